@@ -1,0 +1,173 @@
+/*
+ * mbistft_vits.h — C-ABI of the MI355X-native MB-iSTFT-VITS inference path.
+ *
+ * The reference has no FFI/plugin layer: its boundary for this path is the
+ * Python class surface `models.SynthesizerTrn` (+ `utils.HParams`).  This
+ * header is what a reference-side binding (ctypes) binds
+ * to replace the body of each method; every entry point names the reference
+ * interface it replaces (file:line under the reference repo).
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers + sizes; all tensors are
+ *     fp32, contiguous, [B, C, time] with time fastest (ids/lengths int64).
+ *   - every call returns 0 on success, non-zero on failure; the message is
+ *     available from mbv_last_error().  No C++ exception crosses the ABI.
+ *   - kernels are enqueued on the caller's `stream` (a hipStream_t passed as
+ *     void*; NULL = default stream).  Calls never synchronise the device
+ *     except where stated.
+ *   - a handle is not re-entrant (reference callers are single-threaded
+ *     w.r.t. the model: tts_vits.py:145,181); handles on different devices are
+ *     independent.
+ *   - the library owns only its folded-weight arena and scratch workspace;
+ *     all inputs/outputs are borrowed for the duration of the call.
+ */
+#ifndef MBISTFT_VITS_H
+#define MBISTFT_VITS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBV_ABI_VERSION 1
+
+#define MBV_DEC_MULTIBAND   0   /* models.py:309 Multiband_iSTFT_Generator (fixed PQMF)        */
+#define MBV_DEC_MULTISTREAM 1   /* models.py:387 Multistream_iSTFT_Generator (trainable filter)*/
+
+typedef struct mbv_model mbv_model;   /* opaque */
+
+/* Hyper-parameters: the ctor arguments of models.py:573-599 that shape the
+ * infer path (p_dropout, segment_size, spec_channels, use_sdp, n_layers_q …
+ * do not).  `struct_bytes` must be sizeof(mbv_config). */
+typedef struct mbv_config {
+  int32_t struct_bytes;
+  int32_t n_vocab;
+  int32_t inter_channels;            /* 192 */
+  int32_t hidden_channels;           /* 192 (mini: 96) */
+  int32_t filter_channels;           /* 768 */
+  int32_t n_heads;                   /* 2 */
+  int32_t n_layers;                  /* 6 (mini: 3) */
+  int32_t kernel_size;               /* FFN kernel, 3 */
+  int32_t upsample_initial_channel;  /* 512 (mini: 256) */
+  int32_t resblock_kernel_sizes[3];  /* 3,7,11 */
+  int32_t resblock_dilations[3][3];  /* 1,3,5 each */
+  int32_t n_speakers;                /* 0 = single speaker */
+  int32_t gin_channels;              /* 0 or 256 */
+  int32_t decoder;                   /* MBV_DEC_* */
+  int32_t device;                    /* HIP device ordinal */
+} mbv_config;
+
+/* Output bundle of phase B / decode.  Any pointer may be NULL to skip
+ * materialising that tensor (the reference always returns all of them:
+ * models.py:737).  T' = frames, F = 16 T' + 1, all device pointers. */
+typedef struct mbv_outputs {
+  float *o;        /* [B, 1, 256 T']                         waveform           */
+  float *o_mb;     /* MB: [B, 4, 64 T'];  MS: [B, 4, 256 T'] (zero-stuffed)      */
+  float *spec;     /* [B, 4, 9, F]                                               */
+  float *phase;    /* [B, 4, 9, F]                                               */
+  float *attn;     /* [B, 1, T', T]                          (synthesize only)   */
+  float *y_mask;   /* [B, 1, T']                             (synthesize only)   */
+  float *z;        /* [B, 192, T']                           (synthesize only)   */
+  float *z_p;      /* [B, 192, T']                                               */
+  float *m_p;      /* [B, 192, T']                                               */
+  float *logs_p;   /* [B, 192, T']                                               */
+} mbv_outputs;
+
+/* ---- life cycle ---------------------------------------------------------
+ * replaces SynthesizerTrn.__init__ (models.py:573-655). */
+int  mbv_abi_version(void);
+int  mbv_create(const mbv_config *cfg, mbv_model **out);
+void mbv_destroy(mbv_model *m);
+/* Message of the last failed call on `m` (or of the last failed mbv_create
+ * when m == NULL).  Valid until the next call. */
+const char *mbv_last_error(const mbv_model *m);
+
+/* ---- weights --------------------------------------------------------------
+ * replaces nn.Module.load_state_dict as used by utils.load_checkpoint
+ * (utils.py:22-47).  `name` is the reference state-dict key
+ * ("dec.ups.0.weight_v", …); `data` is a HOST pointer to fp32 values of
+ * `shape[0..ndim)`.  Keys outside the infer path (enc_q.*) are rejected.
+ * mbv_finalize_weights folds weight-norm (w = g v/||v||),
+ * packs every conv for the kernels, uploads once, and may be called again
+ * after further mbv_load_weight calls.  It synchronises `stream`. */
+int mbv_load_weight(mbv_model *m, const char *name, const float *data,
+                    const int64_t *shape, int ndim);
+int mbv_finalize_weights(mbv_model *m, void *stream);
+/* Number of state-dict keys still missing before finalize can succeed;
+ * writes up to `cap` bytes of a comma-separated list into `buf` if non-NULL. */
+int mbv_missing_weights(mbv_model *m, char *buf, size_t cap);
+
+/* ---- phase A: text encoder + duration predictor + durations ---------------
+ * replaces models.py:701-719 (enc_p, emb_g, dp, exp/ceil/sum).
+ *   ids      int64 [B, T]   device     token ids
+ *   lengths  int64 [B]      device     valid tokens per utterance
+ *   sid      int64 [B]      device     speaker ids, NULL iff n_speakers == 0
+ *   y_lengths_out int64 [B] device     frames per utterance (clamped >= 1)
+ * The caller reads max(y_lengths) back (the one host sync of the path,
+ * mirroring commons.py:123) and passes it to mbv_synthesize. */
+int mbv_encode(mbv_model *m, const int64_t *ids, const int64_t *lengths, const int64_t *sid,
+               int B, int T, float length_scale, int64_t *y_lengths_out, void *stream);
+
+/* ---- phase B: length regulation + prior + reverse flow + decoder ----------
+ * replaces models.py:720-734.
+ *   t_frames  T' = max(y_lengths) as read back by the caller
+ *   noise     fp32 [B, 192, T'] standard-normal draws (models.py:729), or NULL
+ *             (== noise_scale 0)
+ *   max_len   decoder input is truncated to this many frames (<=0: none)
+ * Output shapes use T'_dec = min(T', max_len) for o/o_mb/spec/phase. */
+int mbv_synthesize(mbv_model *m, int t_frames, const float *noise, float noise_scale,
+                   int max_len, const mbv_outputs *outs, void *stream);
+
+/* ---- decoder only ----------------------------------------------------------
+ * replaces `net.dec(z, g)` (models.py:344-377 / 430-467; callers
+ * synthesis_module.py:160, chunked decoding notebooks).
+ *   z  fp32 [B, 192, T']   g  fp32 [B, gin, 1] or NULL */
+int mbv_decode(mbv_model *m, const float *z, const float *g, int B, int t_frames,
+               const mbv_outputs *outs, void *stream);
+
+/* speaker embedding lookup: replaces `net.emb_g(sid)` (models.py:705).
+ * out fp32 [B, gin] */
+int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, void *stream);
+
+/* ---- stage timers -----------------------------------------------------------
+ * replaces the `timings` dict (models.py:698-737): milliseconds of the five
+ * stages of the last encode+synthesize pair, from HIP events on `stream`:
+ * [text_encoder, duration_predictor, alignment_and_projection, flow,
+ * waveform_decoder].  Synchronises on the recorded events. */
+int mbv_stage_times_ms(mbv_model *m, float out[5]);
+
+/* ---- stand-alone signal stage ------------------------------------------------
+ * The fused iSTFT + PQMF kernel on its own: replaces TorchSTFT.inverse
+ * (stft.py:197-202) + PQMF.synthesis (pqmf.py:105-116) or the MS tail
+ * (models.py:463-465), including exp / pi*sin of models.py:368-369.
+ *   x_post  fp32 [B, 72, F]  F = 16 T' + 1 (output of subband_conv_post)
+ *   filter  fp32 [4, 63] device synthesis filter, NULL = the PQMF design
+ *   multistream  non-zero: o_mb is the zero-stuffed [B,4,256T'] tensor
+ * Does not need a model handle's weights; `m` provides device + scratch. */
+int mbv_istft_pqmf(mbv_model *m, const float *x_post, int B, int t_frames, const float *filter,
+                   int multistream, float *o, float *o_mb, float *spec, float *phase,
+                   void *stream);
+
+/* ---- introspection (tests, debugging) ---------------------------------------
+ * Copies an internal stage tensor of the last call into `dst` (device).
+ * Names: "x_enc" [B,H,T], "m_text", "logs_text" [B,I,T], "logw", "w_ceil"
+ * [B,1,T], "x_post" [B,72,F], "dec_conv_pre", "dec_up_0", "dec_res_0",
+ * "dec_up_1", "dec_res_1".  Returns the element count, or < 0 on error;
+ * dst == NULL only queries the count. */
+int64_t mbv_read_stage(mbv_model *m, const char *name, float *dst, int64_t capacity,
+                       void *stream);
+
+/* Generic conv1d through the MFMA kernel (tests): y = conv(x, w) + bias,
+ * 'same' padding.  w HOST [Cout, Cin, K], bias HOST [Cout] or NULL,
+ * x/y DEVICE [B, Cin, T] / [B, Cout, T]; in_slope: leaky-relu slope applied
+ * to x first (1 = none). */
+int mbv_op_conv1d(mbv_model *m, const float *x, const float *w_host, const float *bias_host,
+                  float *y, int B, int Cin, int Cout, int T, int K, int dilation,
+                  float in_slope, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBISTFT_VITS_H */

@@ -1,0 +1,218 @@
+// Windowed relative-position self-attention of the text encoder
+// (attentions.py:148-179, helpers :181-243) on the fp32 matrix cores.
+//
+//   s[i,j] = (q_i/sqrt(d)) . k_j + [|j-i|<=4] (q_i/sqrt(d)) . Ek[j-i+4]
+//   s[i,j] = -1e4 where query i or key j is padding           (attentions.py:166)
+//   p      = softmax_j s
+//   o_i    = sum_j p[i,j] v_j + sum_{r=-4..4} p[i,i+r] Ev[r+4]
+//
+// One wave per (32-query tile, head, utterance).  The score tile is computed
+// TRANSPOSED (S^T = K^T Q, keys on the accumulator rows, queries on the lanes)
+// so that (a) both MFMA operands are read time-contiguous straight from the
+// [B, C, T] activations, (b) the softmax reductions run down a lane's own
+// registers (one cross-half shuffle at the end), and (c) the probability tile
+// is already the B operand of the P.V product (O^T = V P^T) with no data
+// movement: k-step s of that product takes accumulator register s.
+// Two passes over the key tiles (max/sum, then normalised P.V) keep P exactly
+// the normalised softmax the reference multiplies by; the contraction cost is
+// negligible at T ~ 200.  The relative-key logits are one extra MFMA tile
+// (rows = the 9 embeddings), the relative-value term is accumulated as 9 band
+// weights per query and applied to O^T at the end.
+#include "kernels.h"
+
+namespace mbv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int acc_row(int reg, int hl) { return (reg & 3) + 8 * (reg >> 2) + 4 * hl; }
+
+template <int DT>
+__global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restrict__ qkv,
+                                                           const float* __restrict__ emb_k,
+                                                           const float* __restrict__ emb_v,
+                                                           const int* __restrict__ lens,
+                                                           float* __restrict__ o, int H, int n_heads,
+                                                           int T) {
+  constexpr int DMAX = DT * 32;
+  constexpr int VS = 33;                              // padded LDS row: conflict-free column reads
+  __shared__ float Vs[DMAX * VS];
+
+  const int lane = threadIdx.x, hl = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int d = H / n_heads;
+  const int tq0 = blockIdx.x * 32;
+  const int tq = tq0 + l31;
+  const int len = lens[b];
+  const float inv = sqrtf((float)d);
+
+  const float* qb = qkv + ((int64_t)b * 3 * H + head * d) * T;
+  const float* kb = qb + (int64_t)H * T;
+  const float* vb = kb + (int64_t)H * T;
+  const int nsteps = d / 2;                           // MFMA k-steps over the head dim
+
+  // Q fragments (B operand): B[k = 2s+hl][j = l31] = q[2s+hl][tq] / sqrt(d)
+  float qf[DMAX / 2];
+#pragma unroll
+  for (int s = 0; s < DMAX / 2; ++s)
+    qf[s] = (s < nsteps && tq < T) ? qb[(int64_t)(2 * s + hl) * T + tq] / inv : 0.f;
+
+  // ---- relative-key logits: R^T[r][tq] = sum_d Ek[r][d] q[d][tq] ------------
+  float rel[9];
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s) {
+      if (s < nsteps) {
+        const float av = l31 < 9 ? emb_k[l31 * d + 2 * s + hl] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], acc, 0, 0, 0);
+      }
+    }
+    // rows 0-3 / 8 live in half 0 (regs 0-3 / 4), rows 4-7 in half 1 (regs 0-3)
+    float mine[5], other[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { mine[k] = acc[k]; other[k] = __shfl_xor(acc[k], 32); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rel[k] = hl == 0 ? mine[k] : other[k];
+      rel[4 + k] = hl == 0 ? other[k] : mine[k];
+    }
+    rel[8] = hl == 0 ? mine[4] : other[4];
+  }
+
+  const int ntiles = (T + 31) / 32;
+  const bool q_valid = tq < len;
+
+  // score tile for key tile kt, masked; rows beyond T get -inf (absent keys)
+  auto score_tile = [&](int kt, f32x16& S) {
+    const int tk0 = kt * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    const int tkl = tk0 + l31;
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s) {
+      if (s < nsteps) {
+        const float av = tkl < T ? kb[(int64_t)(2 * s + hl) * T + tkl] : 0.f;
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], S, 0, 0, 0);
+      }
+    }
+    const bool near = (tk0 - tq0) <= 35 && (tq0 - tk0) <= 35;   // wave-uniform
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tk = tk0 + acc_row(r, hl);
+      float sv = S[r];
+      if (near) {
+        const int rr = tk - tq + 4;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) sv += (rr == q) ? rel[q] : 0.f;
+      }
+      if (!(q_valid && tk < len)) sv = -1e4f;
+      if (tk >= T) sv = -INFINITY;
+      S[r] = sv;
+    }
+  };
+
+  // ---- pass 1: row max and sum ----------------------------------------------
+  float mx = -INFINITY, sum = 0.f;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    f32x16 S;
+    score_tile(kt, S);
+    float tmax = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
+    const float mnew = fmaxf(mx, tmax);
+    if (mnew > -INFINITY) {
+      float part = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part += expf(S[r] - mnew);
+      sum = sum * expf(mx - mnew) + part;     // exp(-inf) = 0 on the first tile
+      mx = mnew;
+    }
+  }
+  {
+    const float mo = __shfl_xor(mx, 32), so = __shfl_xor(sum, 32);
+    const float mall = fmaxf(mx, mo);
+    const float a = mx > -INFINITY ? sum * expf(mx - mall) : 0.f;
+    const float c = mo > -INFINITY ? so * expf(mo - mall) : 0.f;
+    sum = a + c;
+    mx = mall;
+  }
+  const float rsum = 1.f / sum;
+
+  // ---- pass 2: O^T = V P^T, band weights -------------------------------------
+  f32x16 O[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+  float wb[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) wb[q] = 0.f;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int tk0 = kt * 32;
+    f32x16 S;
+    score_tile(kt, S);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = expf(S[r] - mx) * rsum;
+    const bool near = (tk0 - tq0) <= 35 && (tq0 - tk0) <= 35;
+    if (near) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = tk0 + acc_row(r, hl) - tq + 4;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wb[q] += (rr == q) ? S[r] : 0.f;
+      }
+    }
+    // stage V[dd][tk0..tk0+31] -> Vs[dd][.]
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < DMAX / 2; ++it) {
+      const int dd = it * 2 + hl;
+      const int tk = tk0 + l31;
+      Vs[dd * VS + l31] = (dd < d && tk < T) ? vb[(int64_t)dd * T + tk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int tkl = acc_row(s, hl);             // key (within tile) this half supplies at k-step s
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const float av = Vs[(t * 32 + l31) * VS + tkl];
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[s], O[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) wb[q] += __shfl_xor(wb[q], 32);
+
+  // ---- relative values + store ------------------------------------------------
+  float* ob = o + ((int64_t)b * H + head * d) * T;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = t * 32 + acc_row(r, hl);
+      if (dd < d && tq < T) {
+        float v = O[t][r];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v = fmaf(wb[q], emb_v[q * d + dd], v);
+        ob[(int64_t)dd * T + tq] = v;
+      }
+    }
+  }
+}
+
+void launch_rel_attention(const float* qkv, const float* emb_k, const float* emb_v,
+                          const int* lens, float* o, int B, int H, int n_heads, int T,
+                          hipStream_t s) {
+  const int d = H / n_heads;
+  dim3 grid((T + 31) / 32, n_heads, B);
+  if (d <= 32) hipLaunchKernelGGL((rel_attention_kernel<1>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else if (d <= 64) hipLaunchKernelGGL((rel_attention_kernel<2>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else if (d <= 96) hipLaunchKernelGGL((rel_attention_kernel<3>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else hipLaunchKernelGGL((rel_attention_kernel<4>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+}
+
+}  // namespace mbv

@@ -1,0 +1,1027 @@
+// C-ABI (include/mbistft_vits.h) + host orchestration of the infer path.
+// No torch, no exceptions across the boundary; all device work is enqueued on
+// the caller's stream.  Reference call stack being replaced: SURVEY §3.1.
+#include "../../include/mbistft_vits.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mbv;
+
+namespace {
+
+constexpr int kWindow = 4;        // attentions.py:14
+constexpr int kDpFilter = 256;    // models.py:652
+constexpr int kFlowLayers = 4;    // models.py:647
+constexpr int kFlowK = 5;
+constexpr int kNFlows = 4;
+constexpr float kLrelu = 0.1f;    // modules.py:17
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct PConv {              // packed conv living in the weight arena (offsets in floats)
+  size_t w = 0, bias = 0;
+  bool has_bias = false;
+  int M = 0, Mpad = 0, Cin = 0, K = 1;
+};
+struct PVec { size_t off = 0; int n = 0; bool present = false; };
+
+struct StageRef { const float* ptr; int64_t numel; };
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct mbv_model {
+  mbv_config cfg{};
+  std::string err;
+  std::map<std::string, HostTensor> raw;
+  std::map<std::string, std::vector<int64_t>> expected;   // key -> shape
+  bool finalized = false;
+
+  // weight arena
+  std::vector<float> harena;
+  float* darena = nullptr;
+  size_t darena_floats = 0;
+
+  // packed weights
+  struct Layer { PConv qkv, o, ffn1, ffn2; PVec ek, ev, g1, b1, g2, b2; };
+  std::vector<Layer> enc;
+  PVec emb;
+  PConv enc_proj;
+  PConv dp1, dp2;
+  PVec dp_g1, dp_b1, dp_g2, dp_b2, dp_pw, dp_pb, dp_cw, dp_cb;
+  struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers]; PVec cw, cb; };
+  Flow flow[kNFlows];
+  PConv conv_pre, conv_post;
+  struct Up { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, Mpad = 0; } ups[2];
+  struct RB { PConv c1[3], c2[3]; PVec cw, cb; } rb[6];
+  PVec emb_g;
+  PVec filt;                 // [4][4][16] polyphase synthesis filter (x4 gain folded)
+
+  // scratch
+  char* scrA = nullptr; size_t scrA_bytes = 0;
+  char* scrB = nullptr; size_t scrB_bytes = 0;
+  float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
+
+  // state of the last encode
+  int B = 0, T = 0;
+  bool encoded = false, has_g = false;
+  float *x_enc = nullptr, *stats = nullptr, *logw = nullptr, *w_ceil = nullptr, *gvec = nullptr;
+  int *lens32 = nullptr, *cum = nullptr, *ylen32 = nullptr;
+  std::map<std::string, StageRef> stages;
+
+  hipEvent_t ev[7]{};
+  bool ev_ok = false, ev_a = false, ev_b = false;
+
+  int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    err = buf;
+    return 1;
+  }
+  const float* W(size_t off) const { return darena + off; }
+};
+
+#define HIPCHK(m, call)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) return (m)->fail("%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------ key table
+void add_key(mbv_model* m, const std::string& k, std::initializer_list<int64_t> shape) {
+  m->expected[k] = std::vector<int64_t>(shape);
+}
+
+void build_expected(mbv_model* m) {
+  const mbv_config& c = m->cfg;
+  const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels;
+  const int dk = H / c.n_heads, gin = c.gin_channels, C0 = c.upsample_initial_channel;
+  char p[160];
+  add_key(m, "enc_p.emb.weight", {c.n_vocab, H});
+  for (int i = 0; i < c.n_layers; ++i) {
+    snprintf(p, sizeof p, "enc_p.encoder.attn_layers.%d.", i);
+    add_key(m, std::string(p) + "emb_rel_k", {1, 2 * kWindow + 1, dk});
+    add_key(m, std::string(p) + "emb_rel_v", {1, 2 * kWindow + 1, dk});
+    for (const char* n : {"conv_q", "conv_k", "conv_v", "conv_o"}) {
+      add_key(m, std::string(p) + n + ".weight", {H, H, 1});
+      add_key(m, std::string(p) + n + ".bias", {H});
+    }
+    for (int j = 1; j <= 2; ++j) {
+      snprintf(p, sizeof p, "enc_p.encoder.norm_layers_%d.%d.", j, i);
+      add_key(m, std::string(p) + "gamma", {H});
+      add_key(m, std::string(p) + "beta", {H});
+    }
+    snprintf(p, sizeof p, "enc_p.encoder.ffn_layers.%d.", i);
+    add_key(m, std::string(p) + "conv_1.weight", {Fc, H, c.kernel_size});
+    add_key(m, std::string(p) + "conv_1.bias", {Fc});
+    add_key(m, std::string(p) + "conv_2.weight", {H, Fc, c.kernel_size});
+    add_key(m, std::string(p) + "conv_2.bias", {H});
+  }
+  add_key(m, "enc_p.proj.weight", {2 * I, H, 1});
+  add_key(m, "enc_p.proj.bias", {2 * I});
+  if (c.decoder == MBV_DEC_MULTISTREAM) add_key(m, "dec.updown_filter", {4, 4, 4});
+  add_key(m, "dec.conv_pre.bias", {C0});
+  add_key(m, "dec.conv_pre.weight_g", {C0, 1, 1});
+  add_key(m, "dec.conv_pre.weight_v", {C0, I, 7});
+  for (int i = 0; i < 2; ++i) {
+    const int cin = C0 >> i, cout = C0 >> (i + 1);
+    snprintf(p, sizeof p, "dec.ups.%d.", i);
+    add_key(m, std::string(p) + "bias", {cout});
+    add_key(m, std::string(p) + "weight_g", {cin, 1, 1});
+    add_key(m, std::string(p) + "weight_v", {cin, cout, 16});
+  }
+  for (int i = 0; i < 2; ++i) {
+    const int ch = C0 >> (i + 1);
+    for (int j = 0; j < 3; ++j) {
+      const int k = c.resblock_kernel_sizes[j];
+      for (const char* grp : {"convs1", "convs2"})
+        for (int q = 0; q < 3; ++q) {
+          snprintf(p, sizeof p, "dec.resblocks.%d.%s.%d.", i * 3 + j, grp, q);
+          add_key(m, std::string(p) + "bias", {ch});
+          add_key(m, std::string(p) + "weight_g", {ch, 1, 1});
+          add_key(m, std::string(p) + "weight_v", {ch, ch, k});
+        }
+      if (gin) {
+        snprintf(p, sizeof p, "dec.resblocks.%d.cond.", i * 3 + j);
+        add_key(m, std::string(p) + "weight", {ch, gin, 1});
+        add_key(m, std::string(p) + "bias", {ch});
+      }
+    }
+  }
+  add_key(m, "dec.subband_conv_post.bias", {72});
+  add_key(m, "dec.subband_conv_post.weight_g", {72, 1, 1});
+  add_key(m, "dec.subband_conv_post.weight_v", {72, C0 >> 2, 7});
+  if (c.decoder == MBV_DEC_MULTISTREAM) {
+    add_key(m, "dec.multistream_conv_post.weight_g", {1, 1, 1});
+    add_key(m, "dec.multistream_conv_post.weight_v", {1, 4, 63});
+  }
+  for (int f = 0; f < kNFlows; ++f) {
+    snprintf(p, sizeof p, "flow.flows.%d.", 2 * f);
+    const std::string s(p);
+    add_key(m, s + "pre.weight", {H, I / 2, 1});
+    add_key(m, s + "pre.bias", {H});
+    for (int l = 0; l < kFlowLayers; ++l) {
+      const int rs = l < kFlowLayers - 1 ? 2 * H : H;
+      char q[64];
+      snprintf(q, sizeof q, "enc.in_layers.%d.", l);
+      add_key(m, s + q + "bias", {2 * H});
+      add_key(m, s + q + "weight_g", {2 * H, 1, 1});
+      add_key(m, s + q + "weight_v", {2 * H, H, kFlowK});
+      snprintf(q, sizeof q, "enc.res_skip_layers.%d.", l);
+      add_key(m, s + q + "bias", {rs});
+      add_key(m, s + q + "weight_g", {rs, 1, 1});
+      add_key(m, s + q + "weight_v", {rs, H, 1});
+    }
+    if (gin) {
+      add_key(m, s + "enc.cond_layer.bias", {2 * H * kFlowLayers});
+      add_key(m, s + "enc.cond_layer.weight_g", {2 * H * kFlowLayers, 1, 1});
+      add_key(m, s + "enc.cond_layer.weight_v", {2 * H * kFlowLayers, gin, 1});
+    }
+    add_key(m, s + "post.weight", {I / 2, H, 1});
+    add_key(m, s + "post.bias", {I / 2});
+  }
+  add_key(m, "dp.conv_1.weight", {kDpFilter, H, 3});
+  add_key(m, "dp.conv_1.bias", {kDpFilter});
+  add_key(m, "dp.norm_1.gamma", {kDpFilter});
+  add_key(m, "dp.norm_1.beta", {kDpFilter});
+  add_key(m, "dp.conv_2.weight", {kDpFilter, kDpFilter, 3});
+  add_key(m, "dp.conv_2.bias", {kDpFilter});
+  add_key(m, "dp.norm_2.gamma", {kDpFilter});
+  add_key(m, "dp.norm_2.beta", {kDpFilter});
+  add_key(m, "dp.proj.weight", {1, kDpFilter, 1});
+  add_key(m, "dp.proj.bias", {1});
+  if (gin) {
+    add_key(m, "dp.cond.weight", {H, gin, 1});
+    add_key(m, "dp.cond.bias", {H});
+  }
+  if (c.n_speakers > 1) add_key(m, "emb_g.weight", {c.n_speakers, gin});
+}
+
+// ------------------------------------------------------------------ packing
+struct Packer {
+  mbv_model* m;
+  std::vector<float>& a;
+  size_t alloc(size_t n) {
+    const size_t off = align_up(a.size(), 64);
+    a.resize(off + n, 0.f);
+    return off;
+  }
+  const HostTensor& t(const std::string& k) const { return m->raw.at(k); }
+  bool has(const std::string& k) const { return m->raw.count(k) != 0; }
+
+  // conv weight [d0, d1, K] as stored; folds weight-norm over dim 0 if *_v/_g
+  std::vector<float> dense(const std::string& prefix) const {
+    if (has(prefix + ".weight")) return t(prefix + ".weight").data;
+    const HostTensor& v = t(prefix + ".weight_v");
+    const HostTensor& g = t(prefix + ".weight_g");
+    const int64_t d0 = v.shape[0], inner = v.numel() / d0;
+    std::vector<float> w(v.data.size());
+    for (int64_t i = 0; i < d0; ++i) {
+      double n2 = 0;
+      for (int64_t j = 0; j < inner; ++j) { const double x = v.data[i * inner + j]; n2 += x * x; }
+      const float scale = g.data[i] / (float)std::sqrt(n2);
+      for (int64_t j = 0; j < inner; ++j) w[i * inner + j] = v.data[i * inner + j] * scale;
+    }
+    return w;
+  }
+  PVec vec(const std::string& k) {
+    PVec r;
+    if (!has(k)) return r;
+    const HostTensor& x = t(k);
+    r.off = alloc(x.data.size());
+    r.n = (int)x.data.size();
+    r.present = true;
+    std::memcpy(&a[r.off], x.data.data(), x.data.size() * sizeof(float));
+    return r;
+  }
+  PVec vec_data(const std::vector<float>& d) {
+    PVec r;
+    r.off = alloc(d.size()); r.n = (int)d.size(); r.present = true;
+    std::memcpy(&a[r.off], d.data(), d.size() * sizeof(float));
+    return r;
+  }
+  // generic conv: rows[m] -> source output channel (or -1 = zero row), cin_map[ci] -> source ci
+  PConv conv(const std::vector<float>& w, int Cout, int Cin, int K, const std::vector<int>& rows,
+             const std::vector<int>& cin_map, const std::vector<float>* bias,
+             const std::vector<int>* bias_rows) {
+    PConv p;
+    p.M = (int)rows.size(); p.Mpad = (int)align_up(p.M, 128); p.Cin = Cin; p.K = K;
+    p.w = alloc((size_t)K * Cin * p.Mpad);
+    for (int k = 0; k < K; ++k)
+      for (int ci = 0; ci < Cin; ++ci) {
+        float* dst = &a[p.w + ((size_t)k * Cin + ci) * p.Mpad];
+        const int sci = cin_map.empty() ? ci : cin_map[ci];
+        for (int mrow = 0; mrow < p.M; ++mrow) {
+          const int co = rows[mrow];
+          dst[mrow] = co < 0 ? 0.f : w[((size_t)co * Cin + sci) * K + k];
+        }
+      }
+    if (bias) {
+      const std::vector<int>& br = bias_rows ? *bias_rows : rows;
+      p.bias = alloc(br.size());
+      p.has_bias = true;
+      for (size_t i = 0; i < br.size(); ++i) a[p.bias + i] = br[i] < 0 ? 0.f : (*bias)[br[i]];
+    }
+    (void)Cout;
+    return p;
+  }
+  PConv conv_plain(const std::string& prefix) {
+    const std::vector<float> w = dense(prefix);
+    const auto& sh = has(prefix + ".weight") ? t(prefix + ".weight").shape : t(prefix + ".weight_v").shape;
+    const int Cout = (int)sh[0], Cin = (int)sh[1], K = (int)sh[2];
+    std::vector<int> rows(Cout);
+    for (int i = 0; i < Cout; ++i) rows[i] = i;
+    const std::vector<float>* b = has(prefix + ".bias") ? &t(prefix + ".bias").data : nullptr;
+    return conv(w, Cout, Cin, K, rows, {}, b, nullptr);
+  }
+};
+
+// modified Bessel I0 (power series; converges fast for x <= 9)
+double bessel_i0(double x) {
+  double sum = 1.0, term = 1.0;
+  const double q = x * x / 4.0;
+  for (int k = 1; k < 200; ++k) {
+    term *= q / ((double)k * k);
+    sum += term;
+    if (term < 1e-18 * sum) break;
+  }
+  return sum;
+}
+
+// pqmf.py:15-43 + 53-75: Kaiser-windowed prototype, cosine-modulated synthesis bank
+std::vector<float> pqmf_synthesis_filter() {
+  const int taps = 62, K = 4;
+  const double cutoff = 0.15, beta = 9.0;
+  std::vector<double> proto(taps + 1);
+  for (int n = 0; n <= taps; ++n) {
+    const double c = n - 0.5 * taps;
+    double h = n == taps / 2 ? cutoff : std::sin(M_PI * cutoff * c) / (M_PI * c);
+    const double alpha = taps / 2.0;
+    const double r = (n - alpha) / alpha;
+    const double w = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
+    proto[n] = h * w;
+  }
+  std::vector<float> h(K * (taps + 1));
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n <= taps; ++n) {
+      const double sign = (k % 2 == 0) ? 1.0 : -1.0;
+      h[k * (taps + 1) + n] = (float)(2.0 * proto[n] *
+          std::cos((2 * k + 1) * (M_PI / (2.0 * K)) * (n - (taps - 1) / 2.0) - sign * M_PI / 4.0));
+    }
+  return h;
+}
+
+// [band][63] -> polyphase table [band][p][16], x4 up-sampling gain folded in (exact: power of two)
+std::vector<float> polyphase_table(const float* h63) {
+  std::vector<float> t(4 * 64, 0.f);
+  for (int band = 0; band < 4; ++band)
+    for (int p = 0; p < 4; ++p)
+      for (int i = 0; i < 16; ++i) {
+        const int j = 3 - p + 4 * i;
+        t[band * 64 + p * 16 + i] = j <= 62 ? 4.f * h63[band * 63 + j] : 0.f;
+      }
+  return t;
+}
+
+int do_finalize(mbv_model* m, hipStream_t stream) {
+  for (auto& kv : m->expected)
+    if (!m->raw.count(kv.first)) return m->fail("missing weight '%s'", kv.first.c_str());
+  const mbv_config& c = m->cfg;
+  const int H = c.hidden_channels, I = c.inter_channels, gin = c.gin_channels;
+  std::vector<float> arena;
+  Packer P{m, arena};
+  char p[160];
+
+  m->emb = P.vec("enc_p.emb.weight");
+  m->enc.assign(c.n_layers, mbv_model::Layer());
+  for (int i = 0; i < c.n_layers; ++i) {
+    auto& L = m->enc[i];
+    snprintf(p, sizeof p, "enc_p.encoder.attn_layers.%d.", i);
+    const std::string s(p);
+    {   // fused q|k|v 1x1 conv: rows [q(0..H) | k | v]
+      std::vector<float> w(3 * (size_t)H * H), b(3 * (size_t)H);
+      const char* names[3] = {"conv_q", "conv_k", "conv_v"};
+      for (int j = 0; j < 3; ++j) {
+        std::memcpy(&w[(size_t)j * H * H], P.t(s + names[j] + ".weight").data.data(), (size_t)H * H * 4);
+        std::memcpy(&b[(size_t)j * H], P.t(s + names[j] + ".bias").data.data(), (size_t)H * 4);
+      }
+      std::vector<int> rows(3 * H);
+      for (int r = 0; r < 3 * H; ++r) rows[r] = r;
+      L.qkv = P.conv(w, 3 * H, H, 1, rows, {}, &b, nullptr);
+    }
+    L.o = P.conv_plain(s + "conv_o");
+    L.ek = P.vec(s + "emb_rel_k");
+    L.ev = P.vec(s + "emb_rel_v");
+    snprintf(p, sizeof p, "enc_p.encoder.norm_layers_1.%d.", i);
+    L.g1 = P.vec(std::string(p) + "gamma"); L.b1 = P.vec(std::string(p) + "beta");
+    snprintf(p, sizeof p, "enc_p.encoder.norm_layers_2.%d.", i);
+    L.g2 = P.vec(std::string(p) + "gamma"); L.b2 = P.vec(std::string(p) + "beta");
+    snprintf(p, sizeof p, "enc_p.encoder.ffn_layers.%d.", i);
+    L.ffn1 = P.conv_plain(std::string(p) + "conv_1");
+    L.ffn2 = P.conv_plain(std::string(p) + "conv_2");
+  }
+  m->enc_proj = P.conv_plain("enc_p.proj");
+  m->dp1 = P.conv_plain("dp.conv_1");
+  m->dp2 = P.conv_plain("dp.conv_2");
+  m->dp_g1 = P.vec("dp.norm_1.gamma"); m->dp_b1 = P.vec("dp.norm_1.beta");
+  m->dp_g2 = P.vec("dp.norm_2.gamma"); m->dp_b2 = P.vec("dp.norm_2.beta");
+  m->dp_pw = P.vec("dp.proj.weight"); m->dp_pb = P.vec("dp.proj.bias");
+  m->dp_cw = P.vec("dp.cond.weight"); m->dp_cb = P.vec("dp.cond.bias");
+  m->emb_g = P.vec("emb_g.weight");
+
+  // ---- flows: the channel Flip (modules.py:280-287) is folded into the packing.
+  // Reverse pass order is f = 3,2,1,0, each preceded by a flip, so layers 3 and 1
+  // see the physical buffer flipped, 2 and 0 see it straight.
+  const int half = I / 2;
+  for (int f = 0; f < kNFlows; ++f) {
+    auto& F = m->flow[f];
+    const bool flipped = (f % 2) == 1;
+    snprintf(p, sizeof p, "flow.flows.%d.", 2 * f);
+    const std::string s(p);
+    {
+      const std::vector<float> w = P.dense(s + "pre");
+      std::vector<int> rows(H), cmap(half);
+      for (int r = 0; r < H; ++r) rows[r] = r;
+      for (int ci = 0; ci < half; ++ci) cmap[ci] = flipped ? half - 1 - ci : ci;
+      F.pre = P.conv(w, H, half, 1, rows, cmap, &P.t(s + "pre.bias").data, nullptr);
+    }
+    for (int l = 0; l < kFlowLayers; ++l) {
+      char q[64];
+      snprintf(q, sizeof q, "enc.in_layers.%d", l);
+      {   // gated packing: 32-row tiles alternate tanh half / sigmoid half
+        const std::vector<float> w = P.dense(s + q);
+        std::vector<int> rows(2 * H), brows(2 * H);
+        for (int ch = 0; ch < H; ++ch) {
+          rows[(ch / 32) * 64 + (ch % 32)] = ch;
+          rows[(ch / 32) * 64 + 32 + (ch % 32)] = H + ch;
+        }
+        for (int r = 0; r < 2 * H; ++r) brows[r] = r;      // bias stays in reference order
+        F.in[l] = P.conv(w, 2 * H, H, kFlowK, rows, {}, &P.t(s + q + ".bias").data, &brows);
+      }
+      snprintf(q, sizeof q, "enc.res_skip_layers.%d", l);
+      F.rs[l] = P.conv_plain(s + q);
+    }
+    if (gin) {
+      F.cw = P.vec_data(P.dense(s + "enc.cond_layer"));
+      F.cb = P.vec(s + "enc.cond_layer.bias");
+    }
+    {
+      const std::vector<float> w = P.dense(s + "post");
+      std::vector<int> rows(half);
+      for (int r = 0; r < half; ++r) rows[r] = flipped ? half - 1 - r : r;
+      F.post = P.conv(w, half, H, 1, rows, {}, &P.t(s + "post.bias").data, nullptr);
+    }
+  }
+
+  // ---- decoder
+  m->conv_pre = P.conv_plain("dec.conv_pre");
+  for (int i = 0; i < 2; ++i) {
+    snprintf(p, sizeof p, "dec.ups.%d", i);
+    const std::vector<float> w = P.dense(p);            // [Cin][Cout][16], norm per Cin
+    const auto& sh = P.t(std::string(p) + ".weight_v").shape;
+    auto& U = m->ups[i];
+    U.Cin = (int)sh[0]; U.Cout = (int)sh[1]; U.Mpad = (int)align_up(U.Cout, 64);
+    U.w = P.alloc((size_t)16 * U.Cin * U.Mpad);
+    for (int r = 0; r < 4; ++r)
+      for (int j = 0; j < 4; ++j) {
+        const int k = (r + 2) % 4 + 4 * j;
+        for (int ci = 0; ci < U.Cin; ++ci) {
+          float* dst = &arena[U.w + ((size_t)(r * 4 + j) * U.Cin + ci) * U.Mpad];
+          for (int co = 0; co < U.Cout; ++co) dst[co] = w[((size_t)ci * U.Cout + co) * 16 + k];
+        }
+      }
+    U.bias = P.vec(std::string(p) + ".bias").off;
+  }
+  for (int n = 0; n < 6; ++n) {
+    for (int q = 0; q < 3; ++q) {
+      snprintf(p, sizeof p, "dec.resblocks.%d.convs1.%d", n, q);
+      m->rb[n].c1[q] = P.conv_plain(p);
+      snprintf(p, sizeof p, "dec.resblocks.%d.convs2.%d", n, q);
+      m->rb[n].c2[q] = P.conv_plain(p);
+    }
+    if (gin) {
+      snprintf(p, sizeof p, "dec.resblocks.%d.cond.", n);
+      m->rb[n].cw = P.vec(std::string(p) + "weight");
+      m->rb[n].cb = P.vec(std::string(p) + "bias");
+    }
+  }
+  m->conv_post = P.conv_plain("dec.subband_conv_post");
+  if (c.decoder == MBV_DEC_MULTISTREAM) {
+    const std::vector<float> h = P.dense("dec.multistream_conv_post");   // [1][4][63]
+    m->filt = P.vec_data(polyphase_table(h.data()));
+  } else {
+    const std::vector<float> h = pqmf_synthesis_filter();
+    m->filt = P.vec_data(polyphase_table(h.data()));
+  }
+
+  // ---- upload
+  if (m->darena && m->darena_floats < arena.size()) { HIPCHK(m, hipFree(m->darena)); m->darena = nullptr; }
+  if (!m->darena) {
+    HIPCHK(m, hipMalloc((void**)&m->darena, arena.size() * sizeof(float)));
+    m->darena_floats = arena.size();
+  }
+  HIPCHK(m, hipMemcpyAsync(m->darena, arena.data(), arena.size() * sizeof(float),
+                           hipMemcpyHostToDevice, stream));
+  HIPCHK(m, hipStreamSynchronize(stream));
+  m->harena.swap(arena);
+  m->finalized = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------ scratch
+struct Bump {
+  char* base; size_t cap, off = 0;
+  template <typename Tp> Tp* take(size_t n) {
+    off = align_up(off, 256);
+    Tp* p = reinterpret_cast<Tp*>(base + off);
+    off += n * sizeof(Tp);
+    return p;
+  }
+};
+
+int ensure(mbv_model* m, char** buf, size_t* cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*buf) { HIPCHK(m, hipDeviceSynchronize()); HIPCHK(m, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+  need = align_up(need + (need >> 3), 1 << 20);
+  HIPCHK(m, hipMalloc((void**)buf, need));
+  *cap = need;
+  return 0;
+}
+
+ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x_bstride, int Tin,
+                   float* y, int64_t y_bstride, int T, int B, int dil = 1) {
+  ConvArgs a{};
+  a.x = x; a.x_bstride = x_bstride; a.Tin = Tin; a.x_rstride = Tin; a.Cin = p.Cin;
+  a.w = m->W(p.w); a.bias = p.has_bias ? m->W(p.bias) : nullptr;
+  a.M = p.M; a.Mpad = p.Mpad; a.K = p.K; a.dil = dil;
+  a.pad_left = (p.K - 1) * dil / 2;
+  a.in_slope = 1.f;
+  a.y = y; a.y_bstride = y_bstride; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
+  return a;
+}
+
+// decoder + waveform tail on z [B, I, zstride] (first Td frames valid)
+int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, const float* gvec,
+                int B, int Td, const mbv_outputs* outs, hipStream_t s, Bump& sc) {
+  const mbv_config& c = m->cfg;
+  const int I = c.inter_channels, C0 = c.upsample_initial_channel, gin = c.gin_channels;
+  float* x0 = sc.take<float>((size_t)B * C0 * Td);
+  {
+    ConvArgs a = conv_args(m, m->conv_pre, z, (int64_t)I * zstride, Td, x0, (int64_t)C0 * Td, Td, B);
+    a.x_rstride = zstride;
+    a.in_lens = zlens;
+    launch_conv1d(a, s);
+  }
+  m->stages["dec_conv_pre"] = {x0, (int64_t)B * C0 * Td};
+  const float* cur = x0;
+  int L = Td;
+  float* xs = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    const int ch = C0 >> (i + 1);
+    const int Lo = 4 * L;
+    const size_t n = (size_t)B * ch * Lo;
+    float* u = sc.take<float>(n);
+    float* t1 = sc.take<float>(n);
+    float* r = sc.take<float>(n);
+    xs = sc.take<float>(n);
+    {
+      ConvTArgs a{};
+      a.x = cur; a.w = m->W(m->ups[i].w); a.bias = m->W(m->ups[i].bias); a.y = u;
+      a.B = B; a.Cin = m->ups[i].Cin; a.Cout = ch; a.Mpad = m->ups[i].Mpad; a.Tin = L;
+      a.in_slope = kLrelu;
+      launch_convt4(a, s);
+    }
+    m->stages[i == 0 ? "dec_up_0" : "dec_up_1"] = {u, (int64_t)n};
+    for (int j = 0; j < 3; ++j) {
+      const auto& R = m->rb[i * 3 + j];
+      const float* cadd = nullptr;
+      if (gvec && gin && R.cw.present) {           // x = x + cond(g)   (modules.py:214-215)
+        float* cb = sc.take<float>((size_t)B * ch);
+        launch_cond_gemv(gvec, nullptr, nullptr, m->W(R.cw.off), m->W(R.cb.off), cb, B, gin, ch, s);
+        cadd = cb;
+      }
+      const float* state = u;
+      for (int q = 0; q < 3; ++q) {
+        const int d = c.resblock_dilations[j][q];
+        {
+          ConvArgs a = conv_args(m, R.c1[q], state, (int64_t)ch * Lo, Lo, t1, (int64_t)ch * Lo, Lo, B, d);
+          a.in_slope = kLrelu;
+          if (q == 0) a.chan_add = cadd;
+          launch_conv1d(a, s);
+        }
+        {
+          ConvArgs a = conv_args(m, R.c2[q], t1, (int64_t)ch * Lo, Lo, r, (int64_t)ch * Lo, Lo, B, 1);
+          a.in_slope = kLrelu;
+          a.res = state; a.res_bstride = (int64_t)ch * Lo;
+          if (q == 0) a.res_chan_add = cadd;
+          if (q < 2) {
+            a.epi = EPI_RESID;
+          } else {                                   // xs (+)= resblock output ; /3 on the last
+            a.epi = EPI_RESID_ACC;
+            a.y = xs;
+            a.accum_in = j == 0 ? nullptr : xs;
+            a.out_scale = j == 2 ? (1.f / 3.f) : 1.f;
+          }
+          launch_conv1d(a, s);
+        }
+        state = r;
+      }
+    }
+    m->stages[i == 0 ? "dec_res_0" : "dec_res_1"] = {xs, (int64_t)n};
+    cur = xs;
+    L = Lo;
+  }
+  const int Fr = L + 1;
+  const int chl = C0 >> 2;
+  float* xpost = sc.take<float>((size_t)B * 72 * Fr);
+  {
+    ConvArgs a = conv_args(m, m->conv_post, cur, (int64_t)chl * L, L, xpost, (int64_t)72 * Fr, Fr, B);
+    a.in_slope = 0.01f;                              // F.leaky_relu default slope (models.py:363)
+    a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
+    launch_conv1d(a, s);
+  }
+  m->stages["x_post"] = {xpost, (int64_t)B * 72 * Fr};
+  float* o = outs ? outs->o : nullptr;
+  float* otmp = nullptr;
+  if (!o) { otmp = sc.take<float>((size_t)B * 256 * Td); o = otmp; }
+  IstftArgs ia{};
+  ia.x_post = xpost; ia.filt = m->W(m->filt.off); ia.o = o;
+  ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
+  ia.phase = outs ? outs->phase : nullptr;
+  ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
+  launch_istft_pqmf(ia, s);
+  return 0;
+}
+
+size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td) {
+  const size_t C0 = c.upsample_initial_channel;
+  size_t n = (size_t)B * C0 * Td;                              // conv_pre
+  n += 4 * (size_t)B * (C0 / 2) * 4 * Td + 4 * (size_t)B * (C0 / 4) * 16 * Td;
+  n += (size_t)B * 72 * (16 * Td + 1) + (size_t)B * 256 * Td;
+  n += 6 * (size_t)B * C0;                                     // cond vectors
+  return n * sizeof(float) + 64 * 256;
+}
+
+}  // namespace
+
+// ======================================================================== C ABI
+extern "C" {
+
+int mbv_abi_version(void) { return MBV_ABI_VERSION; }
+
+const char* mbv_last_error(const mbv_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+int mbv_create(const mbv_config* cfg, mbv_model** out) {
+  if (!out) { g_create_error = "out is NULL"; return 1; }
+  *out = nullptr;
+  if (!cfg || cfg->struct_bytes != (int32_t)sizeof(mbv_config)) {
+    g_create_error = "mbv_config.struct_bytes does not match this library (ABI mismatch)";
+    return 1;
+  }
+  auto bad = [&](const char* why) { g_create_error = why; return 1; };
+  if (cfg->n_vocab <= 0) return bad("n_vocab must be > 0");
+  if (cfg->hidden_channels % 32 || cfg->inter_channels % 64 || cfg->filter_channels % 32)
+    return bad("hidden/filter channels must be multiples of 32, inter_channels of 64");
+  if (cfg->hidden_channels > kDpFilter) return bad("hidden_channels > 256 not supported (LayerNorm tile)");
+  if (cfg->n_heads <= 0 || cfg->hidden_channels % cfg->n_heads || (cfg->hidden_channels / cfg->n_heads) % 2 ||
+      cfg->hidden_channels / cfg->n_heads > 128)
+    return bad("hidden_channels / n_heads must be an even integer <= 128");
+  if (cfg->upsample_initial_channel % 128) return bad("upsample_initial_channel must be a multiple of 128");
+  if (cfg->decoder != MBV_DEC_MULTIBAND && cfg->decoder != MBV_DEC_MULTISTREAM) return bad("unknown decoder");
+  if (cfg->n_speakers > 1 && cfg->gin_channels <= 0) return bad("n_speakers > 1 needs gin_channels > 0");
+  for (int j = 0; j < 3; ++j)
+    if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0 ||
+        cfg->resblock_kernel_sizes[j] > 15)
+      return bad("resblock kernel sizes must be odd and <= 15");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return bad("no HIP device visible: this library has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
+  if (hipSetDevice(cfg->device) != hipSuccess) return bad("hipSetDevice failed");
+  mbv_model* m = new (std::nothrow) mbv_model();
+  if (!m) return bad("out of host memory");
+  m->cfg = *cfg;
+  build_expected(m);
+  for (auto& e : m->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
+  m->ev_ok = true;
+  *out = m;
+  return 0;
+}
+
+void mbv_destroy(mbv_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->cfg.device);
+  if (m->darena) (void)hipFree(m->darena);
+  if (m->scrA) (void)hipFree(m->scrA);
+  if (m->scrB) (void)hipFree(m->scrB);
+  if (m->user_tab) (void)hipFree(m->user_tab);
+  if (m->ev_ok) for (auto& e : m->ev) (void)hipEventDestroy(e);
+  delete m;
+}
+
+int mbv_load_weight(mbv_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (!m) return 1;
+  if (!name || !data || !shape || ndim <= 0) return m->fail("mbv_load_weight: NULL argument");
+  auto it = m->expected.find(name);
+  if (it == m->expected.end())
+    return m->fail("'%s' is not a weight of the infer path (enc_q.* and training-only keys are not accepted)", name);
+  const auto& want = it->second;
+  bool ok = (int)want.size() == ndim;
+  for (int i = 0; ok && i < ndim; ++i) ok = want[i] == shape[i];
+  if (!ok) {
+    std::string w, g;
+    for (auto v : want) w += std::to_string(v) + ",";
+    for (int i = 0; i < ndim; ++i) g += std::to_string(shape[i]) + ",";
+    return m->fail("shape mismatch for '%s': expected [%s] got [%s]", name, w.c_str(), g.c_str());
+  }
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.assign(data, data + t.numel());
+  m->raw[name] = std::move(t);
+  m->finalized = false;
+  return 0;
+}
+
+int mbv_missing_weights(mbv_model* m, char* buf, size_t cap) {
+  if (!m) return -1;
+  int n = 0;
+  std::string list;
+  for (auto& kv : m->expected)
+    if (!m->raw.count(kv.first)) { ++n; list += kv.first; list += ","; }
+  if (buf && cap) { strncpy(buf, list.c_str(), cap - 1); buf[cap - 1] = 0; }
+  return n;
+}
+
+int mbv_finalize_weights(mbv_model* m, void* stream) {
+  if (!m) return 1;
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  return do_finalize(m, (hipStream_t)stream);
+}
+
+int mbv_speaker_embedding(mbv_model* m, const int64_t* sid, int B, float* out, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized");
+  if (!m->emb_g.present) return m->fail("model has no speaker embedding (n_speakers <= 1)");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  launch_gather_rows(m->W(m->emb_g.off), sid, out, B, m->cfg.gin_channels, m->cfg.n_speakers,
+                     (hipStream_t)stream);
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
+int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const int64_t* sid, int B,
+               int T, float length_scale, int64_t* y_lengths_out, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized (call mbv_finalize_weights)");
+  if (!ids || !lengths || B <= 0 || T <= 0) return m->fail("mbv_encode: bad arguments");
+  const mbv_config& c = m->cfg;
+  if (c.n_speakers > 0 && !sid) return m->fail("sid is required when n_speakers > 0 (models.py:704-705)");
+  if (c.n_speakers > 0 && !m->emb_g.present) return m->fail("n_speakers == 1: the reference has no emb_g either");
+  HIPCHK(m, hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels, gin = c.gin_channels;
+  const size_t BT = (size_t)B * T;
+  size_t need = (BT * (H * 5 + 3 * H + Fc + 2 * I + 2 * kDpFilter + 4) + (size_t)B * (gin + H + 8)) * 4 + 64 * 256;
+  if (ensure(m, &m->scrA, &m->scrA_bytes, need)) return 1;
+  Bump sc{m->scrA, m->scrA_bytes};
+  float* x = sc.take<float>(BT * H);
+  float* x1 = sc.take<float>(BT * H);
+  float* qkv = sc.take<float>(BT * 3 * H);
+  float* att = sc.take<float>(BT * H);
+  float* y = sc.take<float>(BT * H);
+  float* ffn = sc.take<float>(BT * Fc);
+  m->stats = sc.take<float>(BT * 2 * I);
+  float* h1 = sc.take<float>(BT * kDpFilter);
+  float* h2 = sc.take<float>(BT * kDpFilter);
+  m->logw = sc.take<float>(BT);
+  m->w_ceil = sc.take<float>(BT);
+  m->cum = sc.take<int>(BT);
+  m->lens32 = sc.take<int>(B);
+  m->ylen32 = sc.take<int>(B);
+  m->gvec = sc.take<float>((size_t)B * (gin ? gin : 1));
+  float* dpc = sc.take<float>((size_t)B * H);
+  m->stages.clear();
+
+  HIPCHK(m, hipEventRecord(m->ev[0], s));
+  launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, B, T, H, c.n_vocab, s);
+  const int64_t bsH = (int64_t)H * T;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const auto& L = m->enc[i];
+    launch_conv1d(conv_args(m, L.qkv, x, bsH, T, qkv, 3 * bsH, T, B), s);
+    launch_rel_attention(qkv, m->W(L.ek.off), m->W(L.ev.off), m->lens32, att, B, H, c.n_heads, T, s);
+    launch_conv1d(conv_args(m, L.o, att, bsH, T, y, bsH, T, B), s);
+    launch_layernorm(x, y, m->W(L.g1.off), m->W(L.b1.off), x1, B, H, T, 0, nullptr, s);
+    {
+      ConvArgs a = conv_args(m, L.ffn1, x1, bsH, T, ffn, (int64_t)Fc * T, T, B);
+      a.pad_left = (c.kernel_size - 1) / 2;            // attentions.py:296-303
+      a.in_lens = m->lens32; a.relu = 1;
+      launch_conv1d(a, s);
+    }
+    {
+      ConvArgs a = conv_args(m, L.ffn2, ffn, (int64_t)Fc * T, T, y, bsH, T, B);
+      a.pad_left = (c.kernel_size - 1) / 2;
+      a.in_lens = m->lens32; a.out_lens = m->lens32;
+      launch_conv1d(a, s);
+    }
+    const bool last = i == c.n_layers - 1;
+    launch_layernorm(x1, y, m->W(L.g2.off), m->W(L.b2.off), x, B, H, T, 0, last ? m->lens32 : nullptr, s);
+  }
+  m->x_enc = x;
+  {
+    ConvArgs a = conv_args(m, m->enc_proj, x, bsH, T, m->stats, (int64_t)2 * I * T, T, B);
+    a.out_lens = m->lens32;
+    launch_conv1d(a, s);
+  }
+  HIPCHK(m, hipEventRecord(m->ev[1], s));
+
+  // ---- speaker embedding + duration predictor (models.py:704-713)
+  m->has_g = c.n_speakers > 0;
+  const float* cadd = nullptr;
+  if (m->has_g) {
+    launch_gather_rows(m->W(m->emb_g.off), sid, m->gvec, B, gin, c.n_speakers, s);
+    if (m->dp_cw.present) {
+      launch_cond_gemv(m->gvec, nullptr, nullptr, m->W(m->dp_cw.off), m->W(m->dp_cb.off), dpc, B, gin, H, s);
+      cadd = dpc;
+    }
+  }
+  {
+    ConvArgs a = conv_args(m, m->dp1, x, bsH, T, h1, (int64_t)kDpFilter * T, T, B);
+    a.in_lens = m->lens32; a.chan_add = cadd;
+    launch_conv1d(a, s);
+  }
+  launch_layernorm(h1, nullptr, m->W(m->dp_g1.off), m->W(m->dp_b1.off), h2, B, kDpFilter, T, 1, nullptr, s);
+  {
+    ConvArgs a = conv_args(m, m->dp2, h2, (int64_t)kDpFilter * T, T, h1, (int64_t)kDpFilter * T, T, B);
+    a.in_lens = m->lens32;
+    launch_conv1d(a, s);
+  }
+  launch_layernorm(h1, nullptr, m->W(m->dp_g2.off), m->W(m->dp_b2.off), h2, B, kDpFilter, T, 1, nullptr, s);
+  launch_durations(h2, m->W(m->dp_pw.off), m->W(m->dp_pb.off), m->lens32, length_scale, m->logw,
+                   m->w_ceil, m->cum, m->ylen32, y_lengths_out, B, kDpFilter, T, s);
+  HIPCHK(m, hipEventRecord(m->ev[2], s));
+  HIPCHK(m, hipGetLastError());
+  m->B = B; m->T = T; m->encoded = true; m->ev_a = true; m->ev_b = false;
+  m->stages["x_enc"] = {x, (int64_t)BT * H};
+  m->stages["stats"] = {m->stats, (int64_t)BT * 2 * I};
+  m->stages["logw"] = {m->logw, (int64_t)BT};
+  m->stages["w_ceil"] = {m->w_ceil, (int64_t)BT};
+  return 0;
+}
+
+int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_scale, int max_len,
+                   const mbv_outputs* outs, void* stream) {
+  if (!m) return 1;
+  if (!m->encoded) return m->fail("mbv_synthesize without a preceding mbv_encode");
+  if (t_frames <= 0) return m->fail("t_frames must be > 0");
+  const mbv_config& c = m->cfg;
+  HIPCHK(m, hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int B = m->B, T = m->T, Tp = t_frames, H = c.hidden_channels, I = c.inter_channels;
+  const int gin = c.gin_channels;
+  const int Td = (max_len > 0 && max_len < Tp) ? max_len : Tp;
+  const size_t BTp = (size_t)B * Tp;
+  const bool run_dec = outs && (outs->o || outs->o_mb || outs->spec || outs->phase);
+  size_t need = (BTp * (4 * I + 3 * H) + (size_t)B * 2 * H * kFlowLayers) * 4 + 64 * 256 +
+                decoder_scratch_bytes(c, B, Td);
+  if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
+  Bump sc{m->scrB, m->scrB_bytes};
+  for (const char* k : {"dec_conv_pre", "dec_up_0", "dec_up_1", "dec_res_0", "dec_res_1", "x_post"})
+    m->stages.erase(k);
+  float* z = outs && outs->z ? outs->z : sc.take<float>(BTp * I);
+  float* hbuf = sc.take<float>(BTp * H);
+  float* acts = sc.take<float>(BTp * H);
+  float* skip = sc.take<float>(BTp * H);
+  float* gc = sc.take<float>((size_t)B * 2 * H * kFlowLayers);
+
+  HIPCHK(m, hipEventRecord(m->ev[3], s));
+  // m_text / logs_text are the two halves of enc_p.proj's output [B, 2I, T]
+  launch_expand(m->stats, m->stats + (size_t)I * T, (int64_t)2 * I * T, m->cum, m->ylen32,
+                noise_scale != 0.f ? noise : nullptr, noise_scale,
+                outs ? outs->m_p : nullptr, outs ? outs->logs_p : nullptr, outs ? outs->z_p : nullptr, z,
+                outs ? outs->attn : nullptr, outs ? outs->y_mask : nullptr, B, I, T, Tp, s);
+  HIPCHK(m, hipEventRecord(m->ev[4], s));
+
+  // ---- reverse flows, in place on z (models.py:207-214, modules.py:334-353)
+  const int half = I / 2;
+  const int64_t bsI = (int64_t)I * Tp, bsH = (int64_t)H * Tp;
+  for (int f = kNFlows - 1; f >= 0; --f) {
+    const auto& F = m->flow[f];
+    const bool flipped = (f % 2) == 1;
+    float* x0 = flipped ? z + (size_t)half * Tp : z;
+    float* x1 = flipped ? z : z + (size_t)half * Tp;
+    {
+      ConvArgs a = conv_args(m, F.pre, x0, bsI, Tp, hbuf, bsH, Tp, B);
+      a.out_lens = m->ylen32;
+      launch_conv1d(a, s);
+    }
+    const bool cond = m->has_g && gin && F.cw.present;
+    if (cond)
+      launch_cond_gemv(m->gvec, nullptr, nullptr, m->W(F.cw.off), m->W(F.cb.off), gc, B, gin,
+                       2 * H * kFlowLayers, s);
+    for (int l = 0; l < kFlowLayers; ++l) {
+      {
+        ConvArgs a = conv_args(m, F.in[l], hbuf, bsH, Tp, acts, bsH, Tp, B);
+        a.epi = EPI_GATE; a.gate_half = H;
+        if (cond) { a.gate_cond = gc + (size_t)l * 2 * H; a.gate_cond_bstride = 2 * H * kFlowLayers; }
+        launch_conv1d(a, s);
+      }
+      {
+        ConvArgs a = conv_args(m, F.rs[l], acts, bsH, Tp, hbuf, bsH, Tp, B);
+        a.epi = EPI_RES_SKIP; a.out_lens = m->ylen32; a.skip = skip;
+        a.split = l < kFlowLayers - 1 ? H : 0;
+        a.skip_accum = l > 0;
+        launch_conv1d(a, s);
+      }
+    }
+    {
+      ConvArgs a = conv_args(m, F.post, skip, bsH, Tp, x1, bsI, Tp, B);
+      a.in_lens = m->ylen32; a.epi = EPI_COUPLE; a.out_lens = m->ylen32;
+      launch_conv1d(a, s);
+    }
+  }
+  HIPCHK(m, hipEventRecord(m->ev[5], s));
+  if (run_dec) {
+    if (run_decoder(m, z, Tp, m->ylen32, m->has_g ? m->gvec : nullptr, B, Td, outs, s, sc)) return 1;
+  }
+  HIPCHK(m, hipEventRecord(m->ev[6], s));
+  HIPCHK(m, hipGetLastError());
+  m->ev_b = true;
+  return 0;
+}
+
+int mbv_decode(mbv_model* m, const float* z, const float* g, int B, int t_frames,
+               const mbv_outputs* outs, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized");
+  if (!z || B <= 0 || t_frames <= 0 || !outs) return m->fail("mbv_decode: bad arguments");
+  const mbv_config& c = m->cfg;
+  HIPCHK(m, hipSetDevice(c.device));
+  if (ensure(m, &m->scrB, &m->scrB_bytes, decoder_scratch_bytes(c, B, t_frames))) return 1;
+  Bump sc{m->scrB, m->scrB_bytes};
+  m->stages.clear();
+  if (run_decoder(m, z, t_frames, nullptr, (g && c.gin_channels) ? g : nullptr, B, t_frames, outs,
+                  (hipStream_t)stream, sc))
+    return 1;
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
+int mbv_stage_times_ms(mbv_model* m, float out[5]) {
+  if (!m || !out) return 1;
+  if (!m->ev_a || !m->ev_b) return m->fail("no completed encode+synthesize pair to time");
+  HIPCHK(m, hipEventSynchronize(m->ev[6]));
+  HIPCHK(m, hipEventElapsedTime(&out[0], m->ev[0], m->ev[1]));
+  HIPCHK(m, hipEventElapsedTime(&out[1], m->ev[1], m->ev[2]));
+  HIPCHK(m, hipEventElapsedTime(&out[2], m->ev[3], m->ev[4]));
+  HIPCHK(m, hipEventElapsedTime(&out[3], m->ev[4], m->ev[5]));
+  HIPCHK(m, hipEventElapsedTime(&out[4], m->ev[5], m->ev[6]));
+  return 0;
+}
+
+int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const float* filter,
+                   int multistream, float* o, float* o_mb, float* spec, float* phase, void* stream) {
+  if (!m) return 1;
+  if (!x_post || !o || B <= 0 || t_frames <= 0) return m->fail("mbv_istft_pqmf: bad arguments");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  float*& d_tab = m->user_tab;
+  if (!d_tab) HIPCHK(m, hipMalloc((void**)&d_tab, 256 * sizeof(float)));
+  std::vector<float> h63(4 * 63);
+  if (filter) {
+    HIPCHK(m, hipMemcpyAsync(h63.data(), filter, h63.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(m, hipStreamSynchronize(s));
+  } else {
+    h63 = pqmf_synthesis_filter();
+  }
+  const std::vector<float> tab = polyphase_table(h63.data());
+  HIPCHK(m, hipMemcpyAsync(d_tab, tab.data(), 256 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(m, hipStreamSynchronize(s));
+  IstftArgs a{};
+  a.x_post = x_post; a.filt = d_tab; a.o = o; a.o_mb = o_mb; a.spec = spec; a.phase = phase;
+  a.B = B; a.Tp = t_frames; a.multistream = multistream;
+  launch_istft_pqmf(a, s);
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
+int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capacity, void* stream) {
+  if (!m || !name) return -1;
+  const mbv_config& c = m->cfg;
+  std::string n(name);
+  const float* src = nullptr;
+  int64_t numel = 0;
+  // m_text / logs_text are strided halves of `stats` [B, 2I, T]
+  if (n == "m_text" || n == "logs_text") {
+    auto it = m->stages.find("stats");
+    if (it == m->stages.end()) { m->fail("stage '%s' not available", name); return -1; }
+    const int I = c.inter_channels;
+    numel = (int64_t)m->B * I * m->T;
+    if (!dst) return numel;
+    if (capacity < numel) { m->fail("capacity too small"); return -1; }
+    const float* base = it->second.ptr + (n == "logs_text" ? (size_t)I * m->T : 0);
+    if (hipMemcpy2DAsync(dst, (size_t)I * m->T * 4, base, (size_t)2 * I * m->T * 4, (size_t)I * m->T * 4,
+                         m->B, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      m->fail("hipMemcpy2DAsync failed"); return -1;
+    }
+    return numel;
+  }
+  auto it = m->stages.find(n);
+  if (it == m->stages.end()) { m->fail("stage '%s' not available", name); return -1; }
+  src = it->second.ptr; numel = it->second.numel;
+  if (!dst) return numel;
+  if (capacity < numel) { m->fail("capacity too small"); return -1; }
+  if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    m->fail("hipMemcpyAsync failed"); return -1;
+  }
+  return numel;
+}
+
+int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float* bias_host, float* y,
+                  int B, int Cin, int Cout, int T, int K, int dilation, float in_slope, void* stream) {
+  if (!m) return 1;
+  if (Cin % 32) return m->fail("mbv_op_conv1d: Cin must be a multiple of 32");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Mpad = (int)align_up(Cout, 128);
+  std::vector<float> packed((size_t)K * Cin * Mpad, 0.f);
+  for (int k = 0; k < K; ++k)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int co = 0; co < Cout; ++co)
+        packed[((size_t)k * Cin + ci) * Mpad + co] = w_host[((size_t)co * Cin + ci) * K + k];
+  float *dw = nullptr, *db = nullptr;
+  HIPCHK(m, hipMalloc((void**)&dw, packed.size() * 4));
+  HIPCHK(m, hipMemcpy(dw, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  if (bias_host) {
+    HIPCHK(m, hipMalloc((void**)&db, (size_t)Cout * 4));
+    HIPCHK(m, hipMemcpy(db, bias_host, (size_t)Cout * 4, hipMemcpyHostToDevice));
+  }
+  ConvArgs a{};
+  a.x = x; a.x_bstride = (int64_t)Cin * T; a.Tin = T; a.x_rstride = T; a.Cin = Cin;
+  a.w = dw; a.bias = db; a.M = Cout; a.Mpad = Mpad; a.K = K; a.dil = dilation;
+  a.pad_left = (K - 1) * dilation / 2; a.in_slope = in_slope;
+  a.y = y; a.y_bstride = (int64_t)Cout * T; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
+  launch_conv1d(a, s);
+  HIPCHK(m, hipStreamSynchronize(s));
+  HIPCHK(m, hipFree(dw));
+  if (db) HIPCHK(m, hipFree(db));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// conv1d as an implicit GEMM on the gfx950 matrix cores, exact fp32
+// (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, same peak as the
+// fp32 VALU, but one VGPR per operand and the VALU left free for the fused
+// prologue / epilogue).
+//
+//   y[b, m, t] = bias[m] + sum_{ci, tap} Wp[tap][ci][m] * act(x[b, ci, t + tap*dil - pad_left])
+//
+// covers every dense contraction of the path (reference call sites):
+//   attentions.py:139-146 (q/k/v/o 1x1), attentions.py:278-285 (FFN k3),
+//   models.py:128-136 (duration predictor), models.py:178 (enc_p.proj),
+//   modules.py:151-169 (WN in_layers k5 + gate, res_skip 1x1),
+//   modules.py:336-350 (coupling pre/post), models.py:348 (conv_pre k7),
+//   modules.py:216-226 (ResBlock1 convs, leaky-relu fused on the input,
+//   residual add fused on the output), models.py:363-365 (lrelu 0.01 +
+//   ReflectionPad1d((1,0)) + subband_conv_post k7).
+//
+// Tiling (wave64): block = 4 waves as 2(M) x 2(N); each wave owns WM x 2 MFMA
+// tiles of 32x32 (rows = output channels, columns = time, so both operands are
+// read with time / channel on the lane: conflict-free ds_read_b32, coalesced
+// global rows).  K loop: Cin in chunks of CK channels; per chunk the activated
+// input window [CK][128 + halo] and the weight slab [K][CK][BM] are staged in
+// LDS once and reused by all taps.
+#include "kernels.h"
+
+namespace mbv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CONV_BN = 128;
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <int WM, int CK>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
+  constexpr int BM = 64 * WM;
+  constexpr int BN = CONV_BN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * BM;
+  const int t0 = blockIdx.x * BN;
+
+  const int halo = (a.K - 1) * a.dil;
+  const int XL = BN + halo;
+  const int XS = XL;                                  // row stride in floats
+  float* Xs = lds;                                    // [CK][XS]
+  float* Ws = lds + ((CK * XS + 3) & ~3);             // [K][CK][BM]
+
+  f32x16 acc[WM][2];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // number of this wave's 32-row tiles that hold real rows (wave-uniform)
+  const int wrow0 = m0 + wm * 32 * WM;
+  int nact = (a.M - wrow0 + 31) / 32;
+  nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
+
+  const float* xb = a.x + (int64_t)b * a.x_bstride;
+  const int len_in = a.in_lens ? a.in_lens[b] : 0x7fffffff;
+  const int tin_eff = a.reflect1 ? a.Tin + 1 : a.Tin;  // length of the (virtually padded) input
+
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+    __syncthreads();
+    // ---- stage the activated input window ------------------------------
+    for (int r = wave; r < CK; r += 4) {
+      const int ci = ci0 + r;
+      const float* xr = xb + (int64_t)ci * a.x_rstride;
+      const float cadd = a.chan_add ? a.chan_add[b * a.Cin + ci] : 0.f;
+      for (int c = lane; c < XL; c += 64) {
+        int gi = t0 - a.pad_left + c;
+        float v = 0.f;
+        if (gi >= 0 && gi < tin_eff) {
+          if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;
+          v = lrelu(xr[gi] + cadd, a.in_slope);
+          if (gi >= len_in) v = 0.f;
+        }
+        Xs[r * XS + c] = v;
+      }
+    }
+    // ---- stage the weight slab -----------------------------------------
+    {
+      constexpr int Q = BM / 4;
+      const int total = a.K * CK * Q;
+      for (int e = tid; e < total; e += 256) {
+        const int row = e / Q, q = e % Q;
+        const int tap = row / CK, c = row % CK;
+        const float4* src =
+            reinterpret_cast<const float4*>(a.w + ((int64_t)tap * a.Cin + ci0 + c) * a.Mpad + m0) + q;
+        reinterpret_cast<float4*>(Ws + row * BM)[q] = *src;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over taps x channel pairs ---------------------------------
+    if (nact == WM) {
+      for (int tap = 0; tap < a.K; ++tap) {
+        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
+        const float* xrow = Xs + hl * XS + wn * 64 + l31 + tap * a.dil;
+#pragma unroll
+        for (int c2 = 0; c2 < CK / 2; ++c2) {
+          float av[WM], bv[2];
+#pragma unroll
+          for (int i = 0; i < WM; ++i) av[i] = wrow[c2 * 2 * BM + i * 32];
+          bv[0] = xrow[c2 * 2 * XS];
+          bv[1] = xrow[c2 * 2 * XS + 32];
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[1], acc[i][1], 0, 0, 0);
+          }
+        }
+      }
+    } else if (nact == 1) {   // only reachable with WM == 2
+      for (int tap = 0; tap < a.K; ++tap) {
+        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
+        const float* xrow = Xs + hl * XS + wn * 64 + l31 + tap * a.dil;
+#pragma unroll
+        for (int c2 = 0; c2 < CK / 2; ++c2) {
+          const float av = wrow[c2 * 2 * BM];
+          const float b0 = xrow[c2 * 2 * XS];
+          const float b1 = xrow[c2 * 2 * XS + 32];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[0][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------
+  // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int T = a.T;
+  const int len_out = a.out_lens ? a.out_lens[b] : 0x7fffffff;
+  if (a.epi == EPI_GATE) {
+    if constexpr (WM == 2) {
+      if (nact == 2) {
+        const int cbase = (wrow0 >> 6) * 32;            // channel of packed tile pair
+        float* yb = a.y + (int64_t)b * a.y_bstride;
+        const float* gc = a.gate_cond ? a.gate_cond + (int64_t)b * a.gate_cond_bstride : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * hl;
+          if (c >= a.gate_half) continue;
+          float bt = a.bias ? a.bias[c] : 0.f;
+          float bs = a.bias ? a.bias[a.gate_half + c] : 0.f;
+          if (gc) { bt += gc[c]; bs += gc[a.gate_half + c]; }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int t = t0 + wn * 64 + j * 32 + l31;
+            if (t < T) {
+              const float vt = tanhf(acc[0][j][r] + bt);
+              const float vs = sigmoidf_(acc[1][j][r] + bs);
+              yb[(int64_t)c * T + t] = vt * vs;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    if (i >= nact) break;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+      if (row >= a.M) continue;
+      const float bias = a.bias ? a.bias[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = t0 + wn * 64 + j * 32 + l31;
+        if (t >= T) continue;
+        float v = acc[i][j][r] + bias;
+        const float mask = t < len_out ? 1.f : 0.f;
+        switch (a.epi) {
+          case EPI_STORE: {
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.out_lens) v *= mask;
+            a.y[(int64_t)b * a.y_bstride + (int64_t)row * T + t] = v;
+          } break;
+          case EPI_RESID: {
+            float res = a.res[(int64_t)b * a.res_bstride + (int64_t)row * T + t];
+            if (a.res_chan_add) res += a.res_chan_add[b * a.M + row];
+            a.y[(int64_t)b * a.y_bstride + (int64_t)row * T + t] = v + res;
+          } break;
+          case EPI_RESID_ACC: {
+            float res = a.res[(int64_t)b * a.res_bstride + (int64_t)row * T + t];
+            if (a.res_chan_add) res += a.res_chan_add[b * a.M + row];
+            const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
+            float s = v + res;
+            if (a.accum_in) s = a.accum_in[o] + s;
+            a.y[o] = s * a.out_scale;
+          } break;
+          case EPI_RES_SKIP: {
+            if (row < a.split) {
+              const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
+              a.y[o] = (a.y[o] + v) * mask;
+            } else {
+              const int64_t o = ((int64_t)b * (a.M - a.split) + (row - a.split)) * T + t;
+              a.skip[o] = a.skip_accum ? a.skip[o] + v : v;
+            }
+          } break;
+          case EPI_COUPLE: {
+            const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
+            a.y[o] = (a.y[o] - v * mask) * mask;
+          } break;
+          default: break;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int CK>
+static void launch_one(const ConvArgs& a, hipStream_t s) {
+  constexpr int BM = 64 * WM;
+  const int XL = CONV_BN + (a.K - 1) * a.dil;
+  const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM;
+  const size_t lds_bytes = lds_floats * sizeof(float);
+  dim3 grid((a.T + CONV_BN - 1) / CONV_BN, (a.M + BM - 1) / BM, a.B);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, CK>), grid, dim3(256), lds_bytes, s, a);
+}
+
+void launch_conv1d(const ConvArgs& a, hipStream_t s) {
+  const bool wide = a.M > 64 || a.epi == EPI_GATE;
+  // chunk of input channels staged per LDS pass: keep K*CK around 64-96 rows of weights
+  const int ck = a.K >= 7 ? 8 : (a.K >= 2 ? 16 : 32);
+  if (wide) {
+    if (ck == 8) launch_one<2, 8>(a, s);
+    else if (ck == 16) launch_one<2, 16>(a, s);
+    else launch_one<2, 32>(a, s);
+  } else {
+    if (ck == 8) launch_one<1, 8>(a, s);
+    else if (ck == 16) launch_one<1, 16>(a, s);
+    else launch_one<1, 32>(a, s);
+  }
+}
+
+// ============================================================================
+// ConvTranspose1d(k=16, stride=4, padding=6) — models.py:321-323, 352.
+// Polyphase form: output phase r = t mod 4 of frame m = t / 4 is a 4-tap conv
+//   y[co, 4m+r] = bias + sum_ci sum_j W[ci][co][kr + 4j] * act(x[ci, m + sh - j])
+//   kr = (r+2)%4, sh = 1 (r<2) or 2 (r>=2)
+// All four phases share the input window x[m-2 .. m+2]; one wave accumulates the
+// four phase tiles of a (32 co x 32 m) patch so each lane ends up owning four
+// consecutive output samples -> one 16-byte store per lane.
+// ============================================================================
+template <int CK>
+__global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
+  constexpr int BMc = 64;    // output channels per block
+  constexpr int BNm = 64;    // input frames per block
+  constexpr int XS = BNm + 4;
+  __shared__ __attribute__((aligned(16))) float Xs[CK * XS];
+  __shared__ __attribute__((aligned(16))) float Ws[16 * CK * BMc];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, co0 = blockIdx.y * BMc, mb0 = blockIdx.x * BNm;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+  const float* xb = a.x + (int64_t)b * a.Cin * a.Tin;
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+    __syncthreads();
+    for (int e = tid; e < CK * XS; e += 256) {
+      const int r = e / XS, c = e % XS;
+      const int n = mb0 - 2 + c;
+      float v = 0.f;
+      if (n >= 0 && n < a.Tin) v = lrelu(xb[(int64_t)(ci0 + r) * a.Tin + n], a.in_slope);
+      Xs[e] = v;
+    }
+    {
+      constexpr int Q = BMc / 4;
+      for (int e = tid; e < 16 * CK * Q; e += 256) {
+        const int row = e / Q, q = e % Q;      // row = (r*4 + j)*CK + c
+        const int rj = row / CK, c = row % CK;
+        const float4* src = reinterpret_cast<const float4*>(
+            a.w + ((int64_t)rj * a.Cin + ci0 + c) * a.Mpad + co0) + q;
+        reinterpret_cast<float4*>(Ws + row * BMc)[q] = *src;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c2 = 0; c2 < CK / 2; ++c2) {
+      const float* xrow = Xs + (2 * c2 + hl) * XS + wn * 32 + l31;
+      const float* wbase = Ws + (2 * c2 + hl) * BMc + wm * 32 + l31;
+#pragma unroll
+      for (int tau = 0; tau < 5; ++tau) {
+        const float bv = xrow[tau];
+        if (tau <= 3) {
+          const int j = 3 - tau;
+          const float a0 = wbase[((0 * 4 + j) * CK) * BMc];
+          const float a1 = wbase[((1 * 4 + j) * CK) * BMc];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+        }
+        if (tau >= 1) {
+          const int j = 4 - tau;
+          const float a2 = wbase[((2 * 4 + j) * CK) * BMc];
+          const float a3 = wbase[((3 * 4 + j) * CK) * BMc];
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bv, acc[3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int m = mb0 + wn * 32 + l31;
+  if (m < a.Tin) {
+    const int Tout = 4 * a.Tin;
+    float* yb = a.y + (int64_t)b * a.Cout * Tout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+      if (co < a.Cout) {
+        const float bias = a.bias ? a.bias[co] : 0.f;
+        float4 o;
+        o.x = acc[0][r] + bias; o.y = acc[1][r] + bias; o.z = acc[2][r] + bias; o.w = acc[3][r] + bias;
+        *reinterpret_cast<float4*>(yb + (int64_t)co * Tout + 4 * m) = o;
+      }
+    }
+  }
+}
+
+void launch_convt4(const ConvTArgs& a, hipStream_t s) {
+  dim3 grid((a.Tin + 63) / 64, (a.Cout + 63) / 64, a.B);
+  hipLaunchKernelGGL((convt4_mfma_kernel<8>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace mbv

@@ -1,0 +1,120 @@
+// Internal launch interface of the gfx950 kernels (host side, no torch).
+// Layout everywhere: fp32 [B, C, time], time fastest.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbv {
+
+// ---------------------------------------------------------------- conv1d (MFMA)
+// Packed weight layout for the implicit-GEMM kernels: Wp[K][Cin][Mpad], output
+// row m fastest, Mpad a multiple of 64, rows >= M zero.
+enum ConvEpilogue : int {
+  EPI_STORE = 0,     // y = acc + bias  [relu] [*out_mask]
+  EPI_RESID = 1,     // y = acc + bias + res (+chan_add)
+  EPI_RESID_ACC = 2, // y = ((accum_in ? accum_in : 0) + acc + bias + res (+chan_add)) * out_scale
+  EPI_GATE = 3,      // rows come in (tanh-tile, sigmoid-tile) pairs: y[c] = tanh(.)*sigmoid(.)
+  EPI_RES_SKIP = 4,  // row < split: xio = (xio + v) * mask ; else skip[row-split] (+)= v
+  EPI_COUPLE = 5,    // y = (y - (acc + bias) * mask) * mask
+};
+
+struct ConvArgs {
+  // input
+  const float* x;          // [B, Cin, Tin] (+ offsets folded into the pointer)
+  int64_t x_bstride;       // elements between batches
+  int Tin;                 // valid input length (positions >= Tin read as zero padding)
+  int x_rstride;           // elements between channel rows of x (>= Tin)
+  int Cin;
+  // weights
+  const float* w;          // packed [K][Cin][Mpad]
+  const float* bias;       // [M] in packed-row order, or nullptr
+  int M;                   // real output rows (packed order)
+  int Mpad;
+  int K;
+  int dil;
+  int pad_left;            // input index = t + tap*dil - pad_left
+  // prologue
+  float in_slope;          // leaky-relu slope on the input (1 = identity)
+  const int* in_lens;      // if set: input *= (t < in_lens[b])
+  const float* chan_add;   // if set: [B, Cin] added to the input before the activation
+  int reflect1;            // ReflectionPad1d((1,0)) in front of the conv (models.py:364)
+  // output
+  float* y;                // [B, My, T]
+  int64_t y_bstride;
+  int T;                   // output length (row stride of y / res / accum)
+  int epi;
+  int relu;
+  const int* out_lens;     // mask for STORE / RES_SKIP / COUPLE
+  const float* res;        // RESID*: residual [B, M, T]
+  int64_t res_bstride;
+  const float* res_chan_add;  // RESID*: [B, M] added to the residual (ResBlock cond)
+  const float* accum_in;   // RESID_ACC
+  float out_scale;
+  const float* gate_cond;  // GATE: [B, gate_cond_stride] conditioning, already offset to this layer
+  int gate_cond_bstride;
+  int gate_half;           // GATE: H (rows of the tanh half)
+  float* skip;             // RES_SKIP: [B, M - split, T]
+  int split;               // RES_SKIP
+  int skip_accum;          // RES_SKIP: skip += v instead of skip = v
+  int B;
+};
+void launch_conv1d(const ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- ConvTranspose1d k=16 s=4 p=6 (MFMA)
+// Packed: Wt[r][j][Cin][Mpad] with Wt[r][j][ci][co] = W[ci][co][(r+2)%4 + 4j]
+struct ConvTArgs {
+  const float* x;     // [B, Cin, Tin]
+  const float* w;     // packed
+  const float* bias;  // [Cout]
+  float* y;           // [B, Cout, 4*Tin]
+  int B, Cin, Cout, Mpad, Tin;
+  float in_slope;
+};
+void launch_convt4(const ConvTArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- text encoder pieces
+void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
+                  int B, int T, int H, int n_vocab, hipStream_t s);
+// y = LN_c( a (+ r) [relu] ) * gamma + beta  [* mask]
+void launch_layernorm(const float* a, const float* r, const float* gamma, const float* beta,
+                      float* y, int B, int C, int T, int pre_relu, const int* out_lens,
+                      hipStream_t s);
+// windowed relative-position attention, qkv [B, 3H, T] -> o [B, H, T]
+void launch_rel_attention(const float* qkv, const float* emb_k, const float* emb_v,
+                          const int* lens, float* o, int B, int H, int n_heads, int T,
+                          hipStream_t s);
+
+// ---------------------------------------------------------------- durations / length regulation
+// logw = (w . h*mask + b) * mask ; w_ceil = ceil(exp(logw)*mask*scale) ; cum = cumsum ; ylen
+void launch_durations(const float* h, const float* w, const float* b, const int* lens,
+                      float length_scale, float* logw, float* w_ceil, int* cum, int* ylen32,
+                      int64_t* ylen64, int B, int C, int T, hipStream_t s);
+// m_t / logs_t: [B, C, T] views with batch stride src_bstride (halves of the enc_p.proj output)
+void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, const int* cum,
+                   const int* ylen, const float* noise, float noise_scale, float* m_p,
+                   float* logs_p, float* z_p, float* z, float* attn, float* y_mask, int B, int C,
+                   int T, int Tp, hipStream_t s);
+
+// ---------------------------------------------------------------- speaker conditioning
+// out[b][co] = bias[co] + sum_ci W[co][ci] * g[b][ci]   (g = table[sid[b]] if sid)
+void launch_cond_gemv(const float* g, const float* table, const int64_t* sid, const float* W,
+                      const float* bias, float* out, int B, int Cin, int Cout, hipStream_t s);
+void launch_gather_rows(const float* table, const int64_t* sid, float* out, int B, int C,
+                        int n_rows, hipStream_t s);
+
+// ---------------------------------------------------------------- fused iSTFT + PQMF
+struct IstftArgs {
+  const float* x_post;   // [B, 72, F]
+  const float* filt;     // [4][64] device (63 taps + pad), pre-multiplied by the gain 4
+  float* o;              // [B, 256 T']
+  float* o_mb;           // MB: [B,4,64T'] ; MS: [B,4,256T'] zero-stuffed ; or null
+  float* spec;           // [B,4,9,F] or null
+  float* phase;          // [B,4,9,F] or null
+  int B, Tp, multistream;
+};
+void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
+
+// misc
+void launch_fill(float* p, float v, int64_t n, hipStream_t s);
+
+}  // namespace mbv

@@ -1,0 +1,280 @@
+// Small memory-bound pieces of the path: embedding, channel LayerNorm,
+// durations (proj + exp/ceil/cumsum), length regulation, speaker conditioning.
+#include "kernels.h"
+
+namespace mbv {
+
+// ---------------------------------------------------------------------------
+// x[b, c, t] = emb[ids[b,t]][c] * sqrt(H) * (t < len[b])       models.py:173-177
+// Also narrows the int64 lengths to the int32 copy the other kernels use.
+// ---------------------------------------------------------------------------
+__global__ void embed_kernel(const int64_t* ids, const int64_t* lens, const float* emb, float* x,
+                             int* lens32, int B, int T, int H, int n_vocab, float scale) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && c == 0) lens32[b] = (int)lens[b];
+  if (t >= T) return;
+  const int len = (int)lens[b];
+  long long id = ids[(int64_t)b * T + t];
+  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);
+  float v = emb[id * H + c] * scale;
+  x[((int64_t)b * H + c) * T + t] = t < len ? v : 0.f;
+}
+
+void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
+                  int B, int T, int H, int n_vocab, hipStream_t s) {
+  dim3 grid((T + 63) / 64, H, B);
+  hipLaunchKernelGGL(embed_kernel, grid, dim3(64), 0, s, ids, lens, emb, x, lens32, B, T, H, n_vocab,
+                     sqrtf((float)H));
+}
+
+// ---------------------------------------------------------------------------
+// Channel LayerNorm (modules.py:29-32), eps 1e-5, two-pass statistics like
+// F.layer_norm.  Fused: residual add (attentions.py:41,45), ReLU in front
+// (models.py:129-130), mask behind (attentions.py:46).
+// Block = 32 time steps x 8 channel groups; each thread keeps its <= 32
+// channel values in registers, the 8 partials are reduced through LDS.
+// ---------------------------------------------------------------------------
+constexpr int LN_TX = 32, LN_CY = 8, LN_MAXPER = 32;   // C <= 256 (H and the dp filter width)
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* a, const float* r,
+                                                        const float* gamma, const float* beta,
+                                                        float* y, int C, int T, int pre_relu,
+                                                        const int* out_lens) {
+  __shared__ float red[LN_CY][LN_TX];
+  const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * LN_TX + tx;
+  const bool ok = t < T;
+  const int64_t base = (int64_t)b * C * T + t;
+  float v[LN_MAXPER];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPER; ++i) {
+    const int c = cy + i * LN_CY;
+    float x = 0.f;
+    if (ok && c < C) {
+      x = a[base + (int64_t)c * T];
+      if (r) x += r[base + (int64_t)c * T];
+      if (pre_relu) x = fmaxf(x, 0.f);
+    }
+    v[i] = x;
+    sum += x;
+  }
+  red[cy][tx] = sum;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_CY; ++k) mean += red[k][tx];
+  mean /= (float)C;
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPER; ++i) {
+    const int c = cy + i * LN_CY;
+    if (c < C) { const float d = v[i] - mean; sq += d * d; }
+  }
+  red[cy][tx] = sq;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_CY; ++k) var += red[k][tx];
+  const float rstd = rsqrtf(var / (float)C + 1e-5f);
+  const float m = (out_lens && t >= out_lens[b]) ? 0.f : 1.f;
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPER; ++i) {
+    const int c = cy + i * LN_CY;
+    if (c < C) y[base + (int64_t)c * T] = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * m;
+  }
+}
+
+void launch_layernorm(const float* a, const float* r, const float* gamma, const float* beta,
+                      float* y, int B, int C, int T, int pre_relu, const int* out_lens,
+                      hipStream_t s) {
+  dim3 grid((T + LN_TX - 1) / LN_TX, B);
+  hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, s, a, r, gamma, beta, y, C, T, pre_relu,
+                     out_lens);
+}
+
+// ---------------------------------------------------------------------------
+// Durations: dp.proj (C -> 1, models.py:136-137) fused with models.py:717-719:
+//   logw = (w . (h * mask) + b) * mask ; w = exp(logw) * mask * length_scale
+//   w_ceil = ceil(w) ; cum = inclusive cumsum ; y_len = max(sum, 1)
+// One block per utterance; T is scanned in chunks of 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void durations_kernel(const float* h, const float* w,
+                                                        const float* bias, const int* lens,
+                                                        float length_scale, float* logw,
+                                                        float* w_ceil, int* cum, int* ylen32,
+                                                        int64_t* ylen64, int C, int T) {
+  __shared__ int scan[256];
+  __shared__ int carry_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int len = lens[b];
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    int d = 0;
+    if (t < T) {
+      float lw = 0.f, wc = 0.f;
+      if (t < len) {
+        float acc = 0.f;
+        const float* hp = h + (int64_t)b * C * T + t;
+        for (int c = 0; c < C; ++c) acc = fmaf(w[c], hp[(int64_t)c * T], acc);
+        lw = acc + bias[0];
+        wc = ceilf(expf(lw) * length_scale);
+      }
+      logw[(int64_t)b * T + t] = lw;
+      w_ceil[(int64_t)b * T + t] = wc;
+      d = (int)wc;
+    }
+    scan[tid] = d;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {          // Hillis-Steele inclusive scan
+      int v = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (t < T) cum[(int64_t)b * T + t] = carry + scan[tid];
+    __syncthreads();
+    if (tid == 255) carry_s = carry + scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int total = carry_s < 1 ? 1 : carry_s;
+    ylen32[b] = total;
+    if (ylen64) ylen64[b] = total;
+  }
+}
+
+void launch_durations(const float* h, const float* w, const float* b, const int* lens,
+                      float length_scale, float* logw, float* w_ceil, int* cum, int* ylen32,
+                      int64_t* ylen64, int B, int C, int T, hipStream_t s) {
+  hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s, h, w, b, lens, length_scale, logw,
+                     w_ceil, cum, ylen32, ylen64, C, T);
+}
+
+// ---------------------------------------------------------------------------
+// Length regulation (models.py:720-729, commons.py:128-143).  The reference
+// builds a one-hot path [B,1,T',T] and matmuls; it is a gather: frame t' takes
+// token j = first index with cum[j] > t'.  Writes m_p, logs_p, z_p (= m_p +
+// noise * exp(logs_p) * noise_scale), z (copy of z_p: the flows run in place),
+// and optionally the dense attn path and y_mask.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_kernel(const float* m_t, const float* logs_t,
+                                                     int64_t src_bstride, const int* cum,
+                                                     const int* ylen,
+                                                     const float* noise, float noise_scale,
+                                                     float* m_p, float* logs_p, float* z_p, float* z,
+                                                     float* y_mask, int C, int T, int Tp) {
+  const int b = blockIdx.y;
+  const int tp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tp >= Tp) return;
+  const int yl = ylen[b];
+  const int* cb = cum + (int64_t)b * T;
+  int j = -1;
+  if (tp < yl) {
+    int lo = 0, hi = T - 1;                  // first j with cum[j] > tp
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cb[mid] > tp) hi = mid; else lo = mid + 1;
+    }
+    j = cb[lo] > tp ? lo : -1;               // -1: all-zero durations (y_len clamped to 1)
+  }
+  if (y_mask) y_mask[(int64_t)b * Tp + tp] = tp < yl ? 1.f : 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int64_t o = ((int64_t)b * C + c) * Tp + tp;
+    float m = 0.f, lg = 0.f;
+    if (j >= 0) {
+      m = m_t[(int64_t)b * src_bstride + (int64_t)c * T + j];
+      lg = logs_t[(int64_t)b * src_bstride + (int64_t)c * T + j];
+    }
+    float zp = m;
+    if (noise) zp = m + noise[o] * expf(lg) * noise_scale;
+    if (m_p) m_p[o] = m;
+    if (logs_p) logs_p[o] = lg;
+    if (z_p) z_p[o] = zp;
+    z[o] = zp;
+  }
+}
+
+__global__ void attn_path_kernel(const int* cum, const int* ylen, float* attn, int T, int Tp) {
+  // attn[b, 0, tp, t] = 1 iff cum[t-1] <= tp < cum[t] and tp < y_len
+  const int b = blockIdx.z, tp = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int* cb = cum + (int64_t)b * T;
+  const int hi = cb[t], lo = t > 0 ? cb[t - 1] : 0;
+  attn[((int64_t)b * Tp + tp) * T + t] = (tp < ylen[b] && tp >= lo && tp < hi) ? 1.f : 0.f;
+}
+
+void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, const int* cum,
+                   const int* ylen, const float* noise, float noise_scale, float* m_p,
+                   float* logs_p, float* z_p, float* z, float* attn, float* y_mask, int B, int C,
+                   int T, int Tp, hipStream_t s) {
+  dim3 grid((Tp + 255) / 256, B);
+  hipLaunchKernelGGL(expand_kernel, grid, dim3(256), 0, s, m_t, logs_t, src_bstride, cum, ylen, noise,
+                     noise_scale, m_p, logs_p, z_p, z, y_mask, C, T, Tp);
+  if (attn) {
+    dim3 g2((T + 255) / 256, Tp, B);
+    hipLaunchKernelGGL(attn_path_kernel, g2, dim3(256), 0, s, cum, ylen, attn, T, Tp);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Speaker conditioning: 1x1 convs on g [B, gin, 1] are GEMVs
+// (models.py:127 dp.cond, modules.py:152 WN cond_layer, modules.py:215 ResBlock cond).
+// ---------------------------------------------------------------------------
+__global__ void cond_gemv_kernel(const float* g, const float* table, const int64_t* sid,
+                                 const float* W, const float* bias, float* out, int Cin, int Cout) {
+  const int b = blockIdx.y;
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Cout) return;
+  const float* gv = table ? table + sid[b] * Cin : g + (int64_t)b * Cin;
+  const float* wr = W + (int64_t)co * Cin;
+  float acc = 0.f;
+  for (int ci = 0; ci < Cin; ++ci) acc = fmaf(wr[ci], gv[ci], acc);
+  out[(int64_t)b * Cout + co] = acc + (bias ? bias[co] : 0.f);
+}
+
+void launch_cond_gemv(const float* g, const float* table, const int64_t* sid, const float* W,
+                      const float* bias, float* out, int B, int Cin, int Cout, hipStream_t s) {
+  dim3 grid((Cout + 127) / 128, B);
+  hipLaunchKernelGGL(cond_gemv_kernel, grid, dim3(128), 0, s, g, table, sid, W, bias, out, Cin, Cout);
+}
+
+__global__ void gather_rows_kernel(const float* table, const int64_t* sid, float* out, int C,
+                                   int n_rows) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  long long r = sid[b];
+  r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+  out[(int64_t)b * C + c] = table[r * C + c];
+}
+
+void launch_gather_rows(const float* table, const int64_t* sid, float* out, int B, int C,
+                        int n_rows, hipStream_t s) {
+  dim3 grid((C + 127) / 128, B);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(128), 0, s, table, sid, out, C, n_rows);
+}
+
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+void launch_fill(float* p, float v, int64_t n, hipStream_t s) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace mbv

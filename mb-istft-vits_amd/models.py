@@ -1,0 +1,385 @@
+"""Drop-in `models.SynthesizerTrn` for the infer path.
+
+Same constructor signature, attribute names and return tuples as the
+reference (`models.py:573-599`, `697-737`, `742-788`, `.dec` `344-377`), same
+state-dict keys (so `utils.load_checkpoint` and reference checkpoints work),
+but every forward computation happens in the gfx950 kernels behind
+`libmbistft_vits.so`.  PyTorch is used for device memory, the current HIP
+stream and the RNG only.  Training-side methods (`forward`,
+`voice_conversion`) and `enc_q` are out of scope and raise.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _capi
+from .spec import ModelConfig, config_from_ctor, param_shapes, DEC_MS
+
+_STAGES = ("text_encoder", "duration_predictor", "alignment_and_projection", "flow",
+           "waveform_decoder")
+
+
+class _Node(nn.Module):
+    """Parameter container mirroring one reference sub-module (no compute)."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            "this sub-module only holds parameters; the computation runs inside "
+            "SynthesizerTrn.infer / .dec on the HIP path")
+
+
+class _Decoder(_Node):
+    """`net.dec(z, g=None)` -> (y_g_hat, y_mb_hat, spec, phase)  (models.py:344-377 / 430-467)."""
+
+    def forward(self, x, g=None):
+        return self._owner()._decode(x, g)
+
+
+class _SpeakerEmbedding(_Node):
+    """`net.emb_g(sid)` -> [B, gin]  (models.py:654-655, 705)."""
+
+    def forward(self, sid):
+        return self._owner()._speaker_embedding(sid)
+
+
+class Timings(dict):
+    """The reference's `timings` dict (seconds per stage, models.py:698-737),
+    filled lazily from HIP events so that `infer` itself never blocks."""
+
+    def __init__(self, owner, ticket):
+        super().__init__()
+        self._owner, self._ticket, self._done = owner, ticket, False
+
+    def _resolve(self):
+        if not self._done:
+            self._done = True
+            vals = self._owner._stage_times(self._ticket)
+            for k, v in zip(_STAGES, vals):
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        self._resolve()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return len(_STAGES)
+
+    def __contains__(self, k):
+        return k in _STAGES
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+
+class SynthesizerTrn(nn.Module):
+    """Synthesizer (inference path) — constructor surface of `models.py:573-599`."""
+
+    def __init__(self, n_vocab, spec_channels, segment_size, inter_channels, hidden_channels,
+                 filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
+                 resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gen_istft_n_fft,
+                 gen_istft_hop_size, n_speakers=0, gin_channels=0, use_sdp=False,
+                 ms_istft_vits=False, mb_istft_vits=False, subbands=False, istft_vits=False,
+                 **kwargs):
+        super().__init__()
+        self.cfg: ModelConfig = config_from_ctor(
+            n_vocab, spec_channels, segment_size, inter_channels, hidden_channels,
+            filter_channels, n_heads, n_layers, kernel_size, p_dropout, resblock,
+            resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+            upsample_initial_channel, upsample_kernel_sizes, gen_istft_n_fft, gen_istft_hop_size,
+            n_speakers=n_speakers, gin_channels=gin_channels, use_sdp=use_sdp,
+            ms_istft_vits=ms_istft_vits, mb_istft_vits=mb_istft_vits, subbands=subbands,
+            istft_vits=istft_vits)
+        # attributes the reference exposes (models.py:602-624)
+        self.n_vocab, self.spec_channels, self.segment_size = n_vocab, spec_channels, segment_size
+        self.inter_channels, self.hidden_channels = inter_channels, hidden_channels
+        self.filter_channels, self.n_heads, self.n_layers = filter_channels, n_heads, n_layers
+        self.kernel_size, self.p_dropout, self.resblock = kernel_size, p_dropout, resblock
+        self.resblock_kernel_sizes = resblock_kernel_sizes
+        self.resblock_dilation_sizes = resblock_dilation_sizes
+        self.upsample_rates, self.upsample_initial_channel = upsample_rates, upsample_initial_channel
+        self.upsample_kernel_sizes = upsample_kernel_sizes
+        self.n_speakers, self.gin_channels = n_speakers, gin_channels
+        self.ms_istft_vits, self.mb_istft_vits, self.istft_vits = ms_istft_vits, mb_istft_vits, istft_vits
+        self.use_sdp = use_sdp
+
+        self._build_parameter_tree()
+        self._handle = None
+        self._handle_device = None
+        self._synced_sig = None
+        self._ticket = 0
+
+    # ------------------------------------------------------------------ params
+    def _build_parameter_tree(self):
+        from . import synth
+        init = synth.make_state_dict(self.cfg, seed=1234)    # deterministic "random init"
+        roots = {"dec": _Decoder(), "emb_g": _SpeakerEmbedding()}
+        for name, shape in param_shapes(self.cfg).items():
+            parts = name.split(".")
+            node = self
+            for part in parts[:-1]:
+                child = node._modules.get(part)
+                if child is None:
+                    if node is self and part in roots:
+                        child = roots[part]
+                        object.__setattr__(child, "_owner", weakref.ref(self))
+                    else:
+                        child = _Node()
+                    node.add_module(part, child)
+                node = child
+            value = torch.from_numpy(np.ascontiguousarray(init[name]))
+            if name == "dec.updown_filter":
+                node.register_buffer(parts[-1], value)
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(value, requires_grad=False))
+
+    def _weights_signature(self):
+        sig = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    # ------------------------------------------------------------------ handle
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _ensure_handle(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("SynthesizerTrn (MI355X path) has no CPU implementation: move the "
+                               "model to a ROCm device with .to('cuda') before calling infer/dec")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        L = _capi.lib()
+        if self._handle is not None and self._handle_device != idx:
+            L.mbv_destroy(self._handle)
+            self._handle, self._synced_sig = None, None
+        if self._handle is None:
+            c = _capi.MbvConfig()
+            c.struct_bytes = C.sizeof(_capi.MbvConfig)
+            cfg = self.cfg
+            c.n_vocab, c.inter_channels, c.hidden_channels = cfg.n_vocab, cfg.inter_channels, cfg.hidden_channels
+            c.filter_channels, c.n_heads, c.n_layers = cfg.filter_channels, cfg.n_heads, cfg.n_layers
+            c.kernel_size, c.upsample_initial_channel = cfg.kernel_size, cfg.upsample_initial_channel
+            for j in range(3):
+                c.resblock_kernel_sizes[j] = cfg.resblock_kernel_sizes[j]
+                for q in range(3):
+                    c.resblock_dilations[j][q] = cfg.resblock_dilation_sizes[j][q]
+            c.n_speakers, c.gin_channels = cfg.n_speakers, cfg.gin_channels
+            c.decoder = 1 if cfg.decoder == DEC_MS else 0
+            c.device = idx
+            h = C.c_void_p()
+            rc = L.mbv_create(C.byref(c), C.byref(h))
+            if rc:
+                raise _capi.MbvError("mbv_create failed: %s" % L.mbv_last_error(None).decode())
+            self._handle, self._handle_device = h, idx
+        sig = self._weights_signature()
+        if sig != self._synced_sig:
+            self._upload_weights()
+            self._synced_sig = sig
+        return self._handle
+
+    def _upload_weights(self):
+        L = _capi.lib()
+        for name, t in self.state_dict().items():
+            a = t.detach().to(device="cpu", dtype=torch.float32).contiguous().numpy()
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            _capi.check(self._handle, L.mbv_load_weight(self._handle, name.encode(),
+                                                        a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                        "mbv_load_weight(%s)" % name)
+        _capi.check(self._handle, L.mbv_finalize_weights(self._handle, self._stream()),
+                    "mbv_finalize_weights")
+
+    def refresh_weights(self):
+        """Force a re-fold/re-upload (only needed after in-place edits through `.data`)."""
+        self._synced_sig = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._device()).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _capi.lib().mbv_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _check_inputs(self, x, x_lengths, sid):
+        dev = self._device()
+        if x.dim() != 2:
+            raise ValueError("x must be [B, T] token ids")
+        if x_lengths.dim() != 1 or x_lengths.shape[0] != x.shape[0]:
+            raise ValueError("x_lengths must be [B]")
+        x = x.to(device=dev, dtype=torch.int64).contiguous()
+        x_lengths = x_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        if self.n_speakers > 0:
+            if sid is None:
+                raise ValueError("sid is required for a multi-speaker model (models.py:704-705)")
+            sid = sid.to(device=dev, dtype=torch.int64).contiguous()
+            if sid.shape != (x.shape[0],):
+                raise ValueError("sid must be [B]")
+        else:
+            sid = None
+        return x, x_lengths, sid
+
+    def _stage_times(self, ticket):
+        if ticket != self._ticket or self._handle is None:
+            return [float("nan")] * 5               # a later infer re-used the events
+        buf = (C.c_float * 5)()
+        _capi.check(self._handle, _capi.lib().mbv_stage_times_ms(self._handle, C.byref(buf)),
+                    "mbv_stage_times_ms")
+        return [v * 1e-3 for v in buf]              # reference reports seconds
+
+    # ------------------------------------------------------------------ API
+    @torch.no_grad()
+    def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode):
+        h = self._ensure_handle()
+        L = _capi.lib()
+        x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
+        dev, B, T = x.device, x.shape[0], x.shape[1]
+        I = self.cfg.inter_channels
+        with torch.cuda.device(dev):
+            stream = self._stream()
+            y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
+            _capi.check(h, L.mbv_encode(h, self._ptr(x), self._ptr(x_lengths), self._ptr(sid), B, T,
+                                        float(length_scale), self._ptr(y_lengths), stream),
+                        "mbv_encode")
+            Tp = int(y_lengths.max().item())        # the one host sync (commons.py:123)
+            # the reference draws randn_like(m_p) even at noise_scale == 0 (models.py:729)
+            noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)
+            f32 = dict(device=dev, dtype=torch.float32)
+            out = _capi.MbvOutputs()
+            attn = torch.empty(B, 1, Tp, T, **f32)
+            y_mask = torch.empty(B, 1, Tp, **f32)
+            z, z_p = torch.empty(B, I, Tp, **f32), torch.empty(B, I, Tp, **f32)
+            m_p, logs_p = torch.empty(B, I, Tp, **f32), torch.empty(B, I, Tp, **f32)
+            out.attn, out.y_mask = attn.data_ptr(), y_mask.data_ptr()
+            out.z, out.z_p, out.m_p, out.logs_p = z.data_ptr(), z_p.data_ptr(), m_p.data_ptr(), logs_p.data_ptr()
+            o = o_mb = spec = phase = None
+            Td = Tp if max_len is None else max(0, min(Tp, int(max_len)))
+            if decode:
+                if Td <= 0:
+                    raise ValueError("max_len leaves no frames to decode")
+                o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Td, dev)
+                out.o, out.o_mb, out.spec, out.phase = (o.data_ptr(), o_mb.data_ptr(),
+                                                        spec.data_ptr(), phase.data_ptr())
+            self._ticket += 1
+            _capi.check(h, L.mbv_synthesize(h, Tp, self._ptr(noise), float(noise_scale),
+                                            int(Td if max_len is not None else 0), C.byref(out), stream),
+                        "mbv_synthesize")
+        timings = Timings(self, self._ticket)
+        return o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings, y_lengths
+
+    def _alloc_decoder_outputs(self, B, Td, dev):
+        f32 = dict(device=dev, dtype=torch.float32)
+        spf = self.cfg.samples_per_frame
+        o = torch.empty(B, 1, spf * Td, **f32)
+        if self.cfg.decoder == DEC_MS:
+            o_mb = torch.empty(B, 4, spf * Td, **f32)         # zero-stuffed (models.py:463)
+        else:
+            o_mb = torch.empty(B, 4, (spf // 4) * Td, **f32)
+        Fr = 16 * Td + 1
+        spec = torch.empty(B, 4, 9, Fr, **f32)
+        phase = torch.empty(B, 4, 9, Fr, **f32)
+        return o, o_mb, spec, phase
+
+    def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
+              max_len=None):
+        """-> (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:737)"""
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True)
+        return r[:8]
+
+    def infer_z_only(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
+                     max_len=None):
+        """-> (attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:742-788)"""
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, None, decode=False)
+        return r[4], r[5], r[6], r[7]
+
+    def infer_with_lengths(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
+                           max_len=None):
+        """`infer` plus the per-utterance frame counts y_lengths [B] (int64) — what a batched
+        caller needs to trim the padded waveforms (valid samples = 256 * y_lengths)."""
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True)
+        return r[:8], r[8]
+
+    @torch.no_grad()
+    def _decode(self, z, g=None):
+        h = self._ensure_handle()
+        dev = self._device()
+        if z.dim() != 3 or z.shape[1] != self.cfg.inter_channels:
+            raise ValueError("z must be [B, %d, T']" % self.cfg.inter_channels)
+        z = z.to(device=dev, dtype=torch.float32).contiguous()
+        B, _, Tp = z.shape
+        if g is not None:
+            if self.cfg.gin_channels == 0:
+                g = None
+            else:
+                g = g.to(device=dev, dtype=torch.float32).reshape(B, self.cfg.gin_channels).contiguous()
+        with torch.cuda.device(dev):
+            o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Tp, dev)
+            out = _capi.MbvOutputs()
+            out.o, out.o_mb, out.spec, out.phase = o.data_ptr(), o_mb.data_ptr(), spec.data_ptr(), phase.data_ptr()
+            _capi.check(h, _capi.lib().mbv_decode(h, self._ptr(z), self._ptr(g), B, Tp, C.byref(out),
+                                                  self._stream()), "mbv_decode")
+        return o, o_mb, spec, phase
+
+    @torch.no_grad()
+    def _speaker_embedding(self, sid):
+        h = self._ensure_handle()
+        dev = self._device()
+        sid = sid.to(device=dev, dtype=torch.int64).contiguous()
+        flat = sid.reshape(-1)
+        if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= self.n_speakers):
+            raise IndexError("index out of range in self")       # nn.Embedding's message
+        out = torch.empty(flat.numel(), self.cfg.gin_channels, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _capi.check(h, _capi.lib().mbv_speaker_embedding(h, self._ptr(flat), flat.numel(),
+                                                             self._ptr(out), self._stream()),
+                        "mbv_speaker_embedding")
+        return out.reshape(*sid.shape, self.cfg.gin_channels)
+
+    def read_stage(self, name):
+        """Internal stage tensor of the last call as a flat fp32 tensor (tests/debugging)."""
+        h = self._ensure_handle()
+        L = _capi.lib()
+        n = L.mbv_read_stage(h, name.encode(), None, 0, self._stream())
+        if n < 0:
+            raise _capi.MbvError(L.mbv_last_error(h).decode())
+        t = torch.empty(n, device=self._device(), dtype=torch.float32)
+        if L.mbv_read_stage(h, name.encode(), self._ptr(t), n, self._stream()) < 0:
+            raise _capi.MbvError(L.mbv_last_error(h).decode())
+        return t
+
+    # ------------------------------------------------------------------ out of scope
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward (models.py:657-695) is outside the inference "
+                                  "hot path this package implements")
+
+    def voice_conversion(self, *a, **k):
+        raise NotImplementedError("voice_conversion (models.py:790-798) needs the posterior encoder, "
+                                  "which is outside the inference hot path (SURVEY §8f rank 4)")

@@ -1,0 +1,113 @@
+"""-m gpu: the whole `SynthesizerTrn.infer` path on the MI355X vs (a) the golden
+vectors captured from the real reference and (b) the oracle on fresh inputs.
+Bar (north-star): waveform within 1e-4 RMS of the reference CPU path at
+noise_scale=0, length_scale=1; durations (ceil) exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import FIXTURES, load_fixture, config_for, thin, rms
+from oracle import ref_infer as R
+
+pytestmark = pytest.mark.gpu
+
+STAGE_SHAPES = {  # read_stage name -> golden key, shape builder
+    "x_enc": "x_enc", "m_text": "m_text", "logs_text": "logs_text", "logw": "logw",
+    "dec_conv_pre": "dec_conv_pre", "dec_up_0": "dec_up_0", "dec_res_0": "dec_res_0",
+    "dec_up_1": "dec_up_1", "dec_res_1": "dec_res_1", "x_post": "x_post",
+}
+
+
+def _rel(got, ref):
+    return rms(np.asarray(got) - np.asarray(ref)) / max(rms(ref), 1e-3)
+
+
+@pytest.mark.parametrize("fixture", list(FIXTURES))
+def test_infer_matches_reference_golden(fixture):
+    from gpu_util import make_net
+    gold = load_fixture(fixture)
+    net, sd = make_net(FIXTURES[fixture], int(gold["n_vocab"]), int(gold["weight_seed"]))
+    x = torch.from_numpy(gold["x"]).cuda()
+    xl = torch.from_numpy(gold["x_lengths"]).cuda()
+    sid = torch.from_numpy(gold["sid"]).cuda() if "sid" in gold else None
+    o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer(
+        x, xl, sid=sid, noise_scale=0, length_scale=1)
+    B, T = gold["x"].shape
+    Tp = z.shape[-1]
+    report = {}
+    # durations must be exact (ceil discontinuity)
+    assert np.array_equal(attn.sum(2).cpu().numpy(), gold["attn"]), "durations differ"
+    assert np.array_equal(y_mask.cpu().numpy(), gold["y_mask"])
+    shapes = {"x_enc": (B, -1, T), "m_text": (B, -1, T), "logs_text": (B, -1, T), "logw": (B, 1, T),
+              "dec_conv_pre": (B, -1, Tp), "dec_up_0": (B, -1, 4 * Tp), "dec_res_0": (B, -1, 4 * Tp),
+              "dec_up_1": (B, -1, 16 * Tp), "dec_res_1": (B, -1, 16 * Tp), "x_post": (B, 72, 16 * Tp + 1)}
+    for name, shp in shapes.items():
+        got = thin(name, net.read_stage(name).reshape(*shp).cpu()).numpy()
+        report[name] = _rel(got, gold[name])
+    outs = dict(m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, spec=spec, phase=phase, o_mb=o_mb, o=o)
+    for name, t in outs.items():
+        got = thin(name, t.cpu()).numpy()
+        assert got.shape == gold[name].shape, (name, got.shape, gold[name].shape)
+        report[name] = _rel(got, gold[name])
+    print(fixture, {k: "%.1e" % v for k, v in report.items()})
+    for name, r in report.items():
+        assert r < 5e-5, "%s: relative rms error %.3e" % (name, r)
+    err = rms(o.cpu().numpy() - gold["o"])
+    assert err < 1e-4, "waveform rms error %.3e" % err
+    t = dict(timings)
+    assert sorted(t) == sorted(["text_encoder", "duration_predictor", "alignment_and_projection",
+                                "flow", "waveform_decoder"])
+    assert all(v >= 0 for v in t.values())
+
+
+def test_decoder_entry_matches_oracle():
+    """`net.dec(z, g)` (models.py:344-377) on its own, multi-speaker config."""
+    from gpu_util import make_net
+    net, sd = make_net("uudb_ms_istft_vits_ms")
+    rs = np.random.RandomState(3)
+    z = rs.standard_normal((2, 192, 37)).astype(np.float32)
+    sid = torch.tensor([3, 7])
+    g = net.emb_g(sid.cuda()).unsqueeze(-1)
+    assert g.shape == (2, 256, 1)
+    assert torch.equal(g[:, :, 0].cpu(), torch.from_numpy(sd["emb_g.weight"])[sid])
+    o, o_mb, spec, phase = net.dec(torch.from_numpy(z).cuda(), g=g)
+    _, cfg = config_for("uudb_ms_istft_vits_ms")
+    with torch.no_grad():
+        ro, romb, rspec, rphase = R.decode(sd, cfg, torch.from_numpy(z), g.cpu())
+    assert rms(o.cpu().numpy() - ro.numpy()) < 1e-4
+    assert _rel(o_mb.cpu().numpy(), romb.numpy()) < 5e-5
+    assert _rel(spec.cpu().numpy(), rspec.numpy()) < 5e-5
+
+
+def test_infer_vs_oracle_ragged_batch_with_noise_and_maxlen():
+    """Fresh inputs (not in the goldens): ragged batch of 6, noise_scale > 0 with the
+    noise tensor shared with the oracle, length_scale != 1, max_len truncation."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits", seed=1235)
+    x, xl, _ = synth.synthetic_batch(net.cfg, 6, 40, seed=21, ragged=True)
+    torch.manual_seed(0)
+    (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), _), ylen = net.infer_with_lengths(
+        torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda(), noise_scale=0.5, length_scale=1.1,
+        max_len=90)
+    # recover the noise the shim drew: z_p = m_p + noise * exp(logs_p) * 0.5
+    noise = ((z_p - m_p) / (torch.exp(logs_p) * 0.5)).cpu()
+    ref = R.infer(sd, net.cfg, x, xl, None, noise=noise, noise_scale=0.5, length_scale=1.1, max_len=90)
+    assert np.array_equal(ylen.cpu().numpy(), ref["y_lengths"].numpy())
+    assert o.shape == ref["o"].shape
+    assert _rel(z.cpu().numpy(), ref["z"].numpy()) < 5e-5
+    assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
+def test_infer_z_only_and_errors():
+    from gpu_util import make_net
+    net, sd = make_net("ljs_mini_mb_istft_vits")
+    x = torch.randint(1, 59, (2, 9)).cuda()
+    xl = torch.tensor([9, 5]).cuda()
+    attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer_z_only(x, xl, noise_scale=0)
+    full = net.infer(x, xl, noise_scale=0)
+    assert torch.equal(z, full[6][0]) and torch.equal(attn, full[4])
+    with pytest.raises(ValueError):
+        net.infer(x[0], xl)
+    with pytest.raises(NotImplementedError):
+        net(x, xl, None, None)

@@ -1,0 +1,109 @@
+"""-m gpu: kernel-level parity through the C-ABI.
+fp32 tolerances: conv sums of <= 8448 products -> 2e-5 relative to the output RMS;
+iSTFT+PQMF -> 2e-5 absolute on O(1) signals (north-star bar on the waveform is 1e-4 RMS)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_fixture, rms
+from oracle import ref_infer as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    from gpu_util import make_net
+    return make_net("ljs_mini_mb_istft_vits")[0]
+
+
+CONV_CASES = [
+    # B, Cin, Cout, T, K, dil, slope
+    (2, 32, 64, 50, 1, 1, 1.0),
+    (2, 96, 192, 200, 1, 1, 1.0),
+    (3, 192, 576, 131, 1, 1, 1.0),
+    (2, 192, 768, 200, 3, 1, 1.0),
+    (2, 768, 192, 77, 3, 1, 1.0),
+    (2, 192, 384, 300, 5, 1, 1.0),
+    (2, 192, 512, 129, 7, 1, 1.0),
+    (2, 128, 128, 1000, 3, 5, 0.1),
+    (2, 128, 128, 517, 7, 3, 0.1),
+    (1, 128, 128, 1300, 11, 5, 0.1),
+    (2, 256, 256, 260, 11, 1, 0.1),
+    (2, 128, 72, 400, 7, 1, 0.01),
+    (2, 192, 96, 90, 1, 1, 1.0),
+    (1, 64, 64, 5, 3, 1, 0.1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil,slope", CONV_CASES)
+def test_conv1d_mfma(net, B, Cin, Cout, T, K, dil, slope):
+    from gpu_util import op_conv1d
+    rs = np.random.RandomState(B * 1000 + Cin + Cout + T + K)
+    x = rs.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    y = op_conv1d(net, torch.from_numpy(x).cuda(), w, b, K, dil, slope).cpu()
+    xt = torch.from_numpy(x)
+    ref = F.conv1d(F.leaky_relu(xt, slope) if slope != 1.0 else xt, torch.from_numpy(w),
+                   torch.from_numpy(b), padding=(K - 1) * dil // 2, dilation=dil)
+    err = rms((y - ref).numpy())
+    assert err <= 2e-5 * rms(ref.numpy()) + 1e-7, err
+
+
+def test_istft_pqmf_known_answers(net):
+    """Stand-alone kernel vs the reference's TorchSTFT.inverse / PQMF.synthesis vectors:
+    x_post is built so that exp()/pi*sin() reproduce the stored mag/phase."""
+    from gpu_util import op_istft_pqmf
+    rs = np.random.RandomState(5)
+    B, Tp = 3, 7
+    Fr = 16 * Tp + 1
+    x_post = (rs.standard_normal((B, 72, Fr)) * 0.7).astype(np.float32)
+    xt = torch.from_numpy(x_post)
+    W = R.Weights({})
+
+    class Cfg:
+        subbands, gen_istft_n_fft, gen_istft_hop_size = 4, 16, 4
+    o_ref, omb_ref, spec_ref, phase_ref = R.waveform_tail(W, Cfg, xt)
+    o, o_mb, spec, phase = op_istft_pqmf(net, xt.cuda())
+    assert np.abs(spec.cpu().numpy() - spec_ref.numpy()).max() < 1e-5 * float(spec_ref.max())
+    assert np.abs(phase.cpu().numpy() - phase_ref.numpy()).max() < 5e-6
+    assert np.abs(o_mb.cpu().numpy() - omb_ref.numpy()).max() < 2e-5
+    assert np.abs(o.cpu().numpy() - o_ref.numpy()).max() < 2e-5
+    # waveform-only mode gives the same samples
+    o2, _, _, _ = op_istft_pqmf(net, xt.cuda(), extras=False)
+    assert torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("Tp", [1, 2, 29, 30, 31, 61])
+def test_istft_pqmf_tile_edges(net, Tp):
+    """Tile size is 480 sub-band samples = 7.5 z-frames: lengths around tile boundaries."""
+    from gpu_util import op_istft_pqmf
+    rs = np.random.RandomState(Tp)
+    x_post = (rs.standard_normal((2, 72, 16 * Tp + 1)) * 0.7).astype(np.float32)
+    xt = torch.from_numpy(x_post)
+
+    class Cfg:
+        subbands, gen_istft_n_fft, gen_istft_hop_size = 4, 16, 4
+    o_ref, omb_ref, _, _ = R.waveform_tail(R.Weights({}), Cfg, xt)
+    o, o_mb, _, _ = op_istft_pqmf(net, xt.cuda())
+    assert np.abs(o_mb.cpu().numpy() - omb_ref.numpy()).max() < 2e-5
+    assert np.abs(o.cpu().numpy() - o_ref.numpy()).max() < 2e-5
+
+
+def test_istft_pqmf_multistream_filter(net):
+    from gpu_util import op_istft_pqmf
+    rs = np.random.RandomState(11)
+    x_post = (rs.standard_normal((2, 72, 16 * 9 + 1)) * 0.7).astype(np.float32)
+    h = (rs.standard_normal((4, 63)) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x_post)
+    sd = {"dec.multistream_conv_post.weight_v": torch.from_numpy(h)[None],
+          "dec.multistream_conv_post.weight_g": torch.from_numpy(h).norm().reshape(1, 1, 1)}
+
+    class Cfg:
+        subbands, gen_istft_n_fft, gen_istft_hop_size = 4, 16, 4
+    o_ref, up_ref, _, _ = R.waveform_tail(R.Weights(sd), Cfg, xt)
+    o, o_mb, _, _ = op_istft_pqmf(net, xt.cuda(), filt=torch.from_numpy(h).cuda(), multistream=True)
+    assert np.abs(o_mb.cpu().numpy() - up_ref.numpy()).max() < 5e-5
+    assert np.abs(o.cpu().numpy() - o_ref.numpy()).max() < 2e-5
