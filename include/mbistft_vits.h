@@ -138,6 +138,13 @@ int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, v
  * waveform_decoder].  Synchronises on the recorded events. */
 int mbv_stage_times_ms(mbv_model *m, float out[5]);
 
+/* Kernel-level timers of the last mbv_synthesize / mbv_decode (HIP events on the
+ * launch stream, used by bench.py for the roofline lines):
+ *   out[0] = decoder conv stack (conv_pre .. subband_conv_post), ms
+ *   out[1] = the single fused iSTFT+PQMF launch, ms
+ * Synchronises on the recorded events. */
+int mbv_kernel_times_ms(mbv_model *m, float out[2]);
+
 /* ---- stand-alone signal stage ------------------------------------------------
  * The fused iSTFT + PQMF kernel on its own: replaces TorchSTFT.inverse
  * (stft.py:197-202) + PQMF.synthesis (pqmf.py:105-116) or the MS tail

@@ -75,6 +75,7 @@ struct mbv_model {
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
+  bool user_tab_is_pqmf = false;
 
   // state of the last encode
   int B = 0, T = 0;
@@ -84,7 +85,8 @@ struct mbv_model {
   std::map<std::string, StageRef> stages;
 
   hipEvent_t ev[7]{};
-  bool ev_ok = false, ev_a = false, ev_b = false;
+  hipEvent_t evk[3]{};          // decoder start / before istft / after istft
+  bool ev_ok = false, ev_a = false, ev_b = false, evk_set = false;
 
   int fail(const char* fmt, ...) {
     char buf[1024];
@@ -522,6 +524,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   const mbv_config& c = m->cfg;
   const int I = c.inter_channels, C0 = c.upsample_initial_channel, gin = c.gin_channels;
   float* x0 = sc.take<float>((size_t)B * C0 * Td);
+  HIPCHK(m, hipEventRecord(m->evk[0], s));
   {
     ConvArgs a = conv_args(m, m->conv_pre, z, (int64_t)I * zstride, Td, x0, (int64_t)C0 * Td, Td, B);
     a.x_rstride = zstride;
@@ -605,7 +608,10 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
   ia.phase = outs ? outs->phase : nullptr;
   ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
+  HIPCHK(m, hipEventRecord(m->evk[1], s));
   launch_istft_pqmf(ia, s);
+  HIPCHK(m, hipEventRecord(m->evk[2], s));
+  m->evk_set = true;
   return 0;
 }
 
@@ -660,6 +666,8 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   build_expected(m);
   for (auto& e : m->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
+  for (auto& e : m->evk)
+    if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   m->ev_ok = true;
   *out = m;
   return 0;
@@ -672,7 +680,7 @@ void mbv_destroy(mbv_model* m) {
   if (m->scrA) (void)hipFree(m->scrA);
   if (m->scrB) (void)hipFree(m->scrB);
   if (m->user_tab) (void)hipFree(m->user_tab);
-  if (m->ev_ok) for (auto& e : m->ev) (void)hipEventDestroy(e);
+  if (m->ev_ok) { for (auto& e : m->ev) (void)hipEventDestroy(e); for (auto& e : m->evk) (void)hipEventDestroy(e); }
   delete m;
 }
 
@@ -935,6 +943,15 @@ int mbv_stage_times_ms(mbv_model* m, float out[5]) {
   return 0;
 }
 
+int mbv_kernel_times_ms(mbv_model* m, float out[2]) {
+  if (!m || !out) return 1;
+  if (!m->evk_set) return m->fail("no decoder run to time");
+  HIPCHK(m, hipEventSynchronize(m->evk[2]));
+  HIPCHK(m, hipEventElapsedTime(&out[0], m->evk[0], m->evk[1]));
+  HIPCHK(m, hipEventElapsedTime(&out[1], m->evk[1], m->evk[2]));
+  return 0;
+}
+
 int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const float* filter,
                    int multistream, float* o, float* o_mb, float* spec, float* phase, void* stream) {
   if (!m) return 1;
@@ -943,16 +960,19 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   hipStream_t s = (hipStream_t)stream;
   float*& d_tab = m->user_tab;
   if (!d_tab) HIPCHK(m, hipMalloc((void**)&d_tab, 256 * sizeof(float)));
-  std::vector<float> h63(4 * 63);
-  if (filter) {
-    HIPCHK(m, hipMemcpyAsync(h63.data(), filter, h63.size() * 4, hipMemcpyDeviceToHost, s));
+  if (filter || !m->user_tab_is_pqmf) {     // the default PQMF table is uploaded once, then launch-only
+    std::vector<float> h63(4 * 63);
+    if (filter) {
+      HIPCHK(m, hipMemcpyAsync(h63.data(), filter, h63.size() * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(m, hipStreamSynchronize(s));
+    } else {
+      h63 = pqmf_synthesis_filter();
+    }
+    const std::vector<float> tab = polyphase_table(h63.data());
+    HIPCHK(m, hipMemcpyAsync(d_tab, tab.data(), 256 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(m, hipStreamSynchronize(s));
-  } else {
-    h63 = pqmf_synthesis_filter();
+    m->user_tab_is_pqmf = filter == nullptr;
   }
-  const std::vector<float> tab = polyphase_table(h63.data());
-  HIPCHK(m, hipMemcpyAsync(d_tab, tab.data(), 256 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCHK(m, hipStreamSynchronize(s));
   IstftArgs a{};
   a.x_post = x_post; a.filt = d_tab; a.o = o; a.o_mb = o_mb; a.spec = spec; a.phase = phase;
   a.B = B; a.Tp = t_frames; a.multistream = multistream;

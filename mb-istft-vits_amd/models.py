@@ -257,7 +257,8 @@ class SynthesizerTrn(nn.Module):
 
     # ------------------------------------------------------------------ API
     @torch.no_grad()
-    def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode):
+    def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode,
+             frames_hook=None):
         h = self._ensure_handle()
         L = _capi.lib()
         x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
@@ -270,6 +271,8 @@ class SynthesizerTrn(nn.Module):
                                         float(length_scale), self._ptr(y_lengths), stream),
                         "mbv_encode")
             Tp = int(y_lengths.max().item())        # the one host sync (commons.py:123)
+            if frames_hook is not None:             # sharded run: pad to the global T' max
+                Tp = int(frames_hook(Tp))
             # the reference draws randn_like(m_p) even at noise_scale == 0 (models.py:729)
             noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)
             f32 = dict(device=dev, dtype=torch.float32)
@@ -362,6 +365,13 @@ class SynthesizerTrn(nn.Module):
                                                              self._ptr(out), self._stream()),
                         "mbv_speaker_embedding")
         return out.reshape(*sid.shape, self.cfg.gin_channels)
+
+    def kernel_times_ms(self):
+        """(decoder conv stack ms, fused iSTFT+PQMF launch ms) of the last infer / dec call."""
+        buf = (C.c_float * 2)()
+        _capi.check(self._handle, _capi.lib().mbv_kernel_times_ms(self._handle, C.byref(buf)),
+                    "mbv_kernel_times_ms")
+        return float(buf[0]), float(buf[1])
 
     def read_stage(self, name):
         """Internal stage tensor of the last call as a flat fp32 tensor (tests/debugging)."""

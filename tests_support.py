@@ -1,0 +1,35 @@
+"""Small measurement helper shared by bench.py and the profiling scripts."""
+import ctypes as C
+
+import torch
+
+from mb_istft_vits_amd import _capi
+
+
+def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None):
+    """Average duration (ms) of the fused iSTFT+PQMF launch in waveform-only mode on a
+    [B, 72, 16 Tp + 1] input, HIP events on the launch stream."""
+    dev = net._device()
+    h = net._ensure_handle()
+    L = _capi.lib()
+    if x_post is None:
+        g = torch.Generator(device=dev)
+        g.manual_seed(0)
+        x_post = torch.randn(B, 72, 16 * Tp + 1, device=dev, generator=g) * 0.5
+    o = torch.empty(B, 1, 256 * Tp, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def launch():
+        rc = L.mbv_istft_pqmf(h, C.c_void_p(x_post.data_ptr()), B, Tp, None, 0,
+                              C.c_void_p(o.data_ptr()), None, None, None, sp)
+        _capi.check(h, rc, "mbv_istft_pqmf")
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        launch()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
