@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -69,13 +70,14 @@ struct mbv_model {
   struct Up { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, Mpad = 0; } ups[2];
   struct RB { PConv c1[3], c2[3]; PVec cw, cb; } rb[6];
   PVec emb_g;
-  PVec filt;                 // [4][4][16] polyphase synthesis filter (x4 gain folded)
+  PVec filt;                 // synthesis-bank table of the fused iSTFT+PQMF kernel (352 floats)
 
   // scratch
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
   bool user_tab_is_pqmf = false;
+  int exact_math = 0;          // MBV_ISTFT_EXACT=1: libm transcendentals in the iSTFT kernel
 
   // state of the last encode
   int B = 0, T = 0;
@@ -306,19 +308,25 @@ double bessel_i0(double x) {
   return sum;
 }
 
-// pqmf.py:15-43 + 53-75: Kaiser-windowed prototype, cosine-modulated synthesis bank
-std::vector<float> pqmf_synthesis_filter() {
-  const int taps = 62, K = 4;
+// pqmf.py:15-43: Kaiser-windowed sinc prototype (taps 62, cutoff 0.15, beta 9), float64
+std::vector<double> pqmf_prototype() {
+  const int taps = 62;
   const double cutoff = 0.15, beta = 9.0;
   std::vector<double> proto(taps + 1);
   for (int n = 0; n <= taps; ++n) {
     const double c = n - 0.5 * taps;
-    double h = n == taps / 2 ? cutoff : std::sin(M_PI * cutoff * c) / (M_PI * c);
+    const double h = n == taps / 2 ? cutoff : std::sin(M_PI * cutoff * c) / (M_PI * c);
     const double alpha = taps / 2.0;
     const double r = (n - alpha) / alpha;
-    const double w = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
-    proto[n] = h * w;
+    proto[n] = h * bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(beta);
   }
+  return proto;
+}
+
+// pqmf.py:53-75: cosine-modulated synthesis bank h_syn[k][n], float64 -> float32
+std::vector<float> pqmf_synthesis_filter() {
+  const int taps = 62, K = 4;
+  const std::vector<double> proto = pqmf_prototype();
   std::vector<float> h(K * (taps + 1));
   for (int k = 0; k < K; ++k)
     for (int n = 0; n <= taps; ++n) {
@@ -329,15 +337,26 @@ std::vector<float> pqmf_synthesis_filter() {
   return h;
 }
 
-// [band][63] -> polyphase table [band][p][16], x4 up-sampling gain folded in (exact: power of two)
-std::vector<float> polyphase_table(const float* h63) {
-  std::vector<float> t(4 * 64, 0.f);
+// Device table of the fused iSTFT+PQMF kernel (352 floats, layout in istft_pqmf.hip):
+//   generic taps t[band][p][i] = 4 h[band][3 - p + 4 i] (x4 up-sampling gain folded, exact),
+//   and for the fixed PQMF design its factorisation 4 h_k[j] = g[j] * c[k][j mod 8].
+constexpr int kFiltTable = 352;
+std::vector<float> synthesis_table(const float* h63) {
+  std::vector<float> t(kFiltTable, 0.f);
   for (int band = 0; band < 4; ++band)
     for (int p = 0; p < 4; ++p)
       for (int i = 0; i < 16; ++i) {
         const int j = 3 - p + 4 * i;
         t[band * 64 + p * 16 + i] = j <= 62 ? 4.f * h63[band * 63 + j] : 0.f;
       }
+  // fixed-bank factors (pqmf.py:66-75): theta_k(j) = (2k+1)(pi/8)(j - 30.5) - (-1)^k pi/4
+  for (int k = 0; k < 4; ++k)
+    for (int q = 0; q < 8; ++q) {
+      const double sign = (k % 2 == 0) ? 1.0 : -1.0;
+      t[256 + k * 8 + q] = (float)std::cos((2 * k + 1) * (M_PI / 8.0) * (q - 30.5) - sign * M_PI / 4.0);
+    }
+  const std::vector<double> proto = pqmf_prototype();
+  for (int j = 0; j <= 62; ++j) t[288 + j] = (float)(8.0 * proto[j] * (((j / 8) % 2) ? -1.0 : 1.0));
   return t;
 }
 
@@ -466,10 +485,10 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
   m->conv_post = P.conv_plain("dec.subband_conv_post");
   if (c.decoder == MBV_DEC_MULTISTREAM) {
     const std::vector<float> h = P.dense("dec.multistream_conv_post");   // [1][4][63]
-    m->filt = P.vec_data(polyphase_table(h.data()));
+    m->filt = P.vec_data(synthesis_table(h.data()));
   } else {
     const std::vector<float> h = pqmf_synthesis_filter();
-    m->filt = P.vec_data(polyphase_table(h.data()));
+    m->filt = P.vec_data(synthesis_table(h.data()));
   }
 
   // ---- upload
@@ -608,6 +627,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
   ia.phase = outs ? outs->phase : nullptr;
   ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
+  ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math;
   HIPCHK(m, hipEventRecord(m->evk[1], s));
   launch_istft_pqmf(ia, s);
   HIPCHK(m, hipEventRecord(m->evk[2], s));
@@ -663,6 +683,7 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   mbv_model* m = new (std::nothrow) mbv_model();
   if (!m) return bad("out of host memory");
   m->cfg = *cfg;
+  { const char* e = getenv("MBV_ISTFT_EXACT"); m->exact_math = (e && e[0] == '1') ? 1 : 0; }
   build_expected(m);
   for (auto& e : m->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
@@ -959,7 +980,7 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   HIPCHK(m, hipSetDevice(m->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   float*& d_tab = m->user_tab;
-  if (!d_tab) HIPCHK(m, hipMalloc((void**)&d_tab, 256 * sizeof(float)));
+  if (!d_tab) HIPCHK(m, hipMalloc((void**)&d_tab, kFiltTable * sizeof(float)));
   if (filter || !m->user_tab_is_pqmf) {     // the default PQMF table is uploaded once, then launch-only
     std::vector<float> h63(4 * 63);
     if (filter) {
@@ -968,14 +989,15 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
     } else {
       h63 = pqmf_synthesis_filter();
     }
-    const std::vector<float> tab = polyphase_table(h63.data());
-    HIPCHK(m, hipMemcpyAsync(d_tab, tab.data(), 256 * sizeof(float), hipMemcpyHostToDevice, s));
+    const std::vector<float> tab = synthesis_table(h63.data());
+    HIPCHK(m, hipMemcpyAsync(d_tab, tab.data(), kFiltTable * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(m, hipStreamSynchronize(s));
     m->user_tab_is_pqmf = filter == nullptr;
   }
   IstftArgs a{};
   a.x_post = x_post; a.filt = d_tab; a.o = o; a.o_mb = o_mb; a.spec = spec; a.phase = phase;
   a.B = B; a.Tp = t_frames; a.multistream = multistream;
+  a.fixed_bank = filter == nullptr; a.exact_math = m->exact_math;
   launch_istft_pqmf(a, s);
   HIPCHK(m, hipGetLastError());
   return 0;

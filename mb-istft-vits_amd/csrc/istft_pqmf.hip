@@ -7,18 +7,24 @@
 //           (MS: h_syn = weight-normed multistream_conv_post)         models.py:463-465
 //
 // One workgroup owns TM sub-band samples per band (4*TM output samples) of
-// one utterance and runs three phases separated by two barriers:
+// one utterance and runs three phases separated by barriers:
 //   A  one lane per (band, frame): 18 coalesced loads down the frame axis,
-//      exp / pi*sin / sincos, 16-point real inverse DFT (even/odd-bin split),
+//      exp / sin / sincos, 16-point real inverse DFT (even/odd-bin split),
 //      hann window -> LDS  fr[band][n][frame]
-//   B  one lane per (band, 4 consecutive samples): overlap-add of the 4 frames
-//      that cover them, divide by the edge-aware sum of squared windows
-//      (what torch.istft does), zero outside the signal -> LDS ys[band][.]
-//   C  one lane per sub-band sample m: the 4 polyphase outputs o[4m..4m+3]
-//      (<= 16 taps x 4 bands each; the zero-stuffed x4 upsampling never
-//      materialises), one 16-byte store per lane.
-// Frames / samples in the 8/7-sample halos are recomputed, not exchanged;
-// consecutive tiles are mapped to the same XCD so halo rows hit in its L2.
+//   B  one lane per sub-band time index (all 4 bands): overlap-add of the 4
+//      frames that cover it, divide by the edge-aware sum of squared windows
+//      (what torch.istft does), zero outside the signal.
+//      Fixed PQMF bank: the four band samples are immediately rotated into the
+//      8 cosine-modulation phases U_q = sum_k cos(theta_k(q)) y_k  (the bank is
+//      h_k[j] = 2 p[j] cos(theta_k(j)) with theta_k(j+8) = theta_k(j) + (2k+1)pi,
+//      so cos(theta_k(j)) = (-1)^(j/8) cos(theta_k(j mod 8))) -> LDS Us[q][.]
+//      Trainable bank (MS): the band samples go to LDS ys[band][.] as they are.
+//   C  one lane per sub-band sample m: the 4 polyphase outputs o[4m..4m+3];
+//      fixed bank: 16 prototype taps each (64 FMA per lane instead of 252),
+//      trainable bank: <= 16 taps x 4 bands each.  The zero-stuffed x4
+//      upsampling never materialises; one 16-byte store per lane.
+// Frames / samples in the halos are recomputed, not exchanged; consecutive
+// tiles are mapped to the same XCD so halo rows hit in its L2.
 #include "kernels.h"
 
 namespace mbv {
@@ -44,20 +50,53 @@ __device__ constexpr float HANN16[16] = {
     0.5f, 0.69134171618254486f, 0.85355339059327376f, 0.96193976625564337f,
     1.0f, 0.96193976625564337f, 0.85355339059327376f, 0.69134171618254486f,
     0.5f, 0.30865828381745514f, 0.14644660940672624f, 0.03806023374435663f};
+// squared window, for per-lane (runtime-indexed) envelope sums at the signal edges
+__device__ const float WSQ16[16] = {
+    0.0f, 0.0014485813926750633f, 0.021446609406726238f, 0.095269936190567076f,
+    0.25f, 0.47795336526437190f, 0.72855339059327373f, 0.92533011387037270f,
+    1.0f, 0.92533011387037270f, 0.72855339059327373f, 0.47795336526437190f,
+    0.25f, 0.095269936190567076f, 0.021446609406726238f, 0.0014485813926750633f};
+
+template <bool FAST>
+__device__ __forceinline__ void polar(float xm, float xp, float& mag, float& ph, float& re,
+                                      float& im, bool need_im) {
+  if constexpr (FAST) {
+    // hardware transcendentals: v_exp_f32 (2^x), v_sin_f32 / v_cos_f32 (argument in turns).
+    // pi*sin(x) in turns is 0.5*sin(x): no multiply by pi on the path to cos/sin.
+    mag = __builtin_amdgcn_exp2f(xm * 1.44269504088896341f);
+    const float t = xp * 0.15915494309189535f;
+    const float s = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+    ph = kPi * s;
+    re = mag * __builtin_amdgcn_cosf(0.5f * s);
+    im = need_im ? mag * __builtin_amdgcn_sinf(0.5f * s) : 0.f;
+  } else {
+    mag = expf(xm);
+    ph = kPi * sinf(xp);
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    re = mag * cs;
+    im = mag * sn;
+  }
+}
 
 }  // namespace
 
-// filt: [band][p][16] with filt[band][p][i] = 4 * h[band][3 - p + 4 i]  (0 where the tap is > 62)
-template <int TM, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS) void istft_pqmf_kernel(const IstftArgs a, int tiles_per_utt,
+// Table `filt` (device, 320 floats):
+//   [0, 256)    trainable-bank polyphase taps  t[band][p][i] = 4 h[band][3 - p + 4 i]
+//   [256, 288)  fixed bank: c[k][q] = cos(theta_k(q)), k < 4, q < 8
+//   [288, 352)  fixed bank: g[j] = 8 p[j] (-1)^(j/8), j < 63 (g[63] = 0)
+template <int TM, int NTHREADS, bool FIXED, bool FAST>
+__global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, int tiles_per_utt,
                                                               int total_tiles) {
   constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
-  constexpr int NFS = TM / 4 + 8;         // padded frame stride in LDS
+  constexpr int NFS = ((NF + 31) / 32) * 32 + 8;   // LDS frame stride, == 8 (mod 32): conflict-free phase B
   constexpr int YL = TM + 16;             // sub-band samples incl. PQMF halo
+  constexpr int NROW = FIXED ? 8 : 4;     // rows of the phase-B product (U_q or y_band)
   static_assert(4 * NF <= NTHREADS, "one lane per (band, frame)");
-  static_assert(TM <= NTHREADS, "one lane per sub-band sample");
+  static_assert(YL <= NTHREADS, "one lane per sub-band time index");
+  static_assert(NROW * YL <= 4 * 16 * NFS, "phase-B product aliases the frame buffer");
   __shared__ __attribute__((aligned(16))) float fr[4 * 16 * NFS];
-  __shared__ __attribute__((aligned(16))) float ys[4 * YL];
+  float* const prod = fr;                 // reused after the frames are consumed
 
   // XCD-aware tile order: workgroups with equal (id % 8) share an L2; give each
   // of the 8 groups a contiguous run of tiles so halo rows are re-read on-die.
@@ -89,12 +128,8 @@ __global__ __launch_bounds__(NTHREADS) void istft_pqmf_kernel(const IstftArgs a,
       const bool own = (4 * f >= m0 && 4 * f < m0 + TM) || (f == F - 1 && m0 + TM >= M);
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float mag = expf(xin[k]);
-        const float ph = kPi * sinf(xin[9 + k]);
-        float sn, cs;
-        sincosf(ph, &sn, &cs);
-        re[k] = mag * cs;
-        im[k] = mag * sn;
+        float mag, ph;
+        polar<FAST>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
         if (own) {
           if (a.spec) a.spec[(((int64_t)b * 4 + band) * 9 + k) * F + f] = mag;
           if (a.phase) a.phase[(((int64_t)b * 4 + band) * 9 + k) * F + f] = ph;
@@ -122,43 +157,60 @@ __global__ __launch_bounds__(NTHREADS) void istft_pqmf_kernel(const IstftArgs a,
   }
   __syncthreads();
 
-  // ---------------- phase B: overlap-add + envelope -----------------------
-  if (tid < YL) {                         // 4 bands x YL/4 quads == YL work items
-    constexpr int QB = YL / 4;            // quads per band
-    const int band = tid / QB, q = tid % QB;
-    // quad q covers m = m0 - 8 + 4q + r ; f' = m0/4 - 2 + q ; frames f'-1 .. f'+2
-    const int fbase = q;                  // local index of frame f'-1  (f_lo = m0/4 - 3)
+  // ---------------- phase B: overlap-add + envelope (+ modulation) ---------
+  float rowv[NROW];
+  {
+    const int u = tid;                    // m = m0 - 8 + u
+    const int q = u >> 2, r = u & 3;      // quad f' = m0/4 - 2 + q ; frames f'-1 .. f'+2
+    const int m = m0 - 8 + u;
     const int fp = m0 / 4 - 2 + q;
-    float y[4];
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    if (u < YL && m >= 0 && m < M) {
+      float env;
+      if (fp - 1 >= 0 && fp + 2 < F) {
+        env = 1.5f;                        // sum of squared hann over 4 overlapping frames
+      } else {
+        env = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = 0.f, env = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {       // frame f'-1+g contributes its sample n = 12 - 4g + r
-        const int n = 12 - 4 * g + r;
-        const int f = fp - 1 + g;
-        // q <= YL/4 - 1 = TM/4 + 3 and g <= 3 -> local frame index <= NF - 1
-        s += fr[(band * 16 + n) * NFS + fbase + g];
-        env += (f >= 0 && f < F) ? HANN16[n] * HANN16[n] : 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const int f = fp - 1 + g;
+          env += (f >= 0 && f < F) ? WSQ16[12 - 4 * g + r] : 0.f;
+        }
       }
-      const int m = m0 - 8 + 4 * q + r;
-      y[r] = (m >= 0 && m < M) ? s / env : 0.f;
-    }
-    *reinterpret_cast<float4*>(&ys[band * YL + 4 * q]) = make_float4(y[0], y[1], y[2], y[3]);
-    if (a.o_mb && q >= 2 && q < QB - 2) {          // owned samples m0 .. m0+TM-1
-      const int m = m0 - 8 + 4 * q;
-      if (m < M) {
-        if (!a.multistream) {
-          *reinterpret_cast<float4*>(a.o_mb + ((int64_t)b * 4 + band) * M + m) =
-              make_float4(y[0], y[1], y[2], y[3]);
-        } else {                                    // zero-stuffed x4, gain 4 (models.py:463)
-          float* dst = a.o_mb + ((int64_t)b * 4 + band) * 4 * M + 4 * (int64_t)m;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            reinterpret_cast<float4*>(dst)[r] = make_float4(4.f * y[r], 0.f, 0.f, 0.f);
+      for (int band = 0; band < 4; ++band) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)      // frame f'-1+g contributes its sample n = 12 - 4g + r
+          s += fr[(band * 16 + 12 - 4 * g + r) * NFS + q + g];
+        y[band] = s / env;
+      }
+      if (a.o_mb && u >= 8 && u < TM + 8) {          // owned samples m0 .. m0+TM-1
+        if (!a.multistream) {
+#pragma unroll
+          for (int band = 0; band < 4; ++band) a.o_mb[((int64_t)b * 4 + band) * M + m] = y[band];
+        } else {                                       // zero-stuffed x4, gain 4 (models.py:463)
+#pragma unroll
+          for (int band = 0; band < 4; ++band)
+            *reinterpret_cast<float4*>(a.o_mb + ((int64_t)b * 4 + band) * 4 * M + 4 * (int64_t)m) =
+                make_float4(4.f * y[band], 0.f, 0.f, 0.f);
         }
       }
     }
+    if constexpr (FIXED) {
+      const float* c = a.filt + 256;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq)
+        rowv[qq] = c[qq] * y[0] + c[8 + qq] * y[1] + c[16 + qq] * y[2] + c[24 + qq] * y[3];
+    } else {
+#pragma unroll
+      for (int band = 0; band < 4; ++band) rowv[band] = y[band];
+    }
+  }
+  __syncthreads();                        // every lane has consumed its frames: reuse the buffer
+  if (tid < YL) {
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) prod[k * YL + tid] = rowv[k];
   }
   __syncthreads();
 
@@ -167,15 +219,27 @@ __global__ __launch_bounds__(NTHREADS) void istft_pqmf_kernel(const IstftArgs a,
     const int m = m0 + tid;
     if (m < M) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (FIXED) {
+        const float* g = a.filt + 288;
 #pragma unroll
-      for (int band = 0; band < 4; ++band) {
-        const float* yb = &ys[band * YL + tid + 1];        // y[m - 7 + i]
-        const float* hb = a.filt + band * 64;
+        for (int p = 0; p < 4; ++p) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float yv = yb[i];
+          for (int i = 0; i < 16; ++i) {
+            const int j = 3 - p + 4 * i;           // tap index; y index m - 7 + i
+            if (j <= 62) acc[p] = fmaf(g[j], prod[(j & 7) * YL + tid + 1 + i], acc[p]);
+          }
+        }
+      } else {
 #pragma unroll
-          for (int p = 0; p < 4; ++p) acc[p] = fmaf(hb[p * 16 + i], yv, acc[p]);
+        for (int band = 0; band < 4; ++band) {
+          const float* yb = &prod[band * YL + tid + 1];        // y[m - 7 + i]
+          const float* hb = a.filt + band * 64;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float yv = yb[i];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[p] = fmaf(hb[p * 16 + i], yv, acc[p]);
+          }
         }
       }
       *reinterpret_cast<float4*>(a.o + (int64_t)b * 4 * M + 4 * (int64_t)m) =
@@ -189,8 +253,14 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
   const int M = 64 * a.Tp;
   const int tiles_per_utt = (M + TM - 1) / TM;
   const int total = tiles_per_utt * a.B;
-  hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT>), dim3(total), dim3(NT), 0, s, a, tiles_per_utt,
-                     total);
+  const dim3 grid(total), block(NT);
+  if (a.fixed_bank) {
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, false>), grid, block, 0, s, a, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, true>), grid, block, 0, s, a, tiles_per_utt, total);
+  } else {
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, false>), grid, block, 0, s, a, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, true>), grid, block, 0, s, a, tiles_per_utt, total);
+  }
 }
 
 }  // namespace mbv

@@ -105,12 +105,14 @@ void launch_gather_rows(const float* table, const int64_t* sid, float* out, int 
 // ---------------------------------------------------------------- fused iSTFT + PQMF
 struct IstftArgs {
   const float* x_post;   // [B, 72, F]
-  const float* filt;     // [4][64] device (63 taps + pad), pre-multiplied by the gain 4
+  const float* filt;     // 352-float device table, see istft_pqmf.hip (generic taps | c[k][q] | g[j])
   float* o;              // [B, 256 T']
   float* o_mb;           // MB: [B,4,64T'] ; MS: [B,4,256T'] zero-stuffed ; or null
   float* spec;           // [B,4,9,F] or null
   float* phase;          // [B,4,9,F] or null
   int B, Tp, multistream;
+  int fixed_bank;        // 1: the PQMF design (cosine-modulated, factorised); 0: arbitrary 4x63 taps
+  int exact_math;        // 1: libm expf/sinf/sincosf instead of the hardware transcendentals
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
 

@@ -107,3 +107,31 @@ def test_istft_pqmf_multistream_filter(net):
     o, o_mb, _, _ = op_istft_pqmf(net, xt.cuda(), filt=torch.from_numpy(h).cuda(), multistream=True)
     assert np.abs(o_mb.cpu().numpy() - up_ref.numpy()).max() < 5e-5
     assert np.abs(o.cpu().numpy() - o_ref.numpy()).max() < 2e-5
+
+
+def test_istft_fast_vs_exact_transcendentals():
+    """The default kernel uses v_exp/v_sin/v_cos; MBV_ISTFT_EXACT=1 selects libm.  Both must sit
+    well inside the 1e-4 RMS bar; this pins how far apart they are on O(1) signals with
+    phase pre-activations up to |x| ~ 12 (range reduction)."""
+    import os
+    from gpu_util import make_net, op_istft_pqmf
+    rs = np.random.RandomState(17)
+    x_post = (rs.standard_normal((4, 72, 16 * 40 + 1))).astype(np.float32)
+    x_post[:, 9::18] *= 4.0                      # large phase arguments on one bin per band
+    xt = torch.from_numpy(x_post).cuda()
+    os.environ["MBV_ISTFT_EXACT"] = "1"
+    try:
+        net_exact = make_net("ljs_mini_mb_istft_vits")[0]
+        o_exact = op_istft_pqmf(net_exact, xt)[0].cpu().numpy()
+    finally:
+        os.environ.pop("MBV_ISTFT_EXACT")
+    net_fast = make_net("ljs_mini_mb_istft_vits")[0]
+    o_fast = op_istft_pqmf(net_fast, xt)[0].cpu().numpy()
+
+    class Cfg:
+        subbands, gen_istft_n_fft, gen_istft_hop_size = 4, 16, 4
+    o_ref = R.waveform_tail(R.Weights({}), Cfg, torch.from_numpy(x_post))[0].numpy()
+    e_exact, e_fast = rms(o_exact - o_ref), rms(o_fast - o_ref)
+    print("istft rms err vs oracle: exact %.2e fast %.2e (signal rms %.2f)" % (e_exact, e_fast, rms(o_ref)))
+    assert e_exact < 2e-5 * max(1.0, rms(o_ref))
+    assert e_fast < 2e-5 * max(1.0, rms(o_ref))
