@@ -57,6 +57,38 @@ __device__ const float WSQ16[16] = {
     1.0f, 0.92533011387037270f, 0.72855339059327373f, 0.47795336526437190f,
     0.25f, 0.095269936190567076f, 0.021446609406726238f, 0.0014485813926750633f};
 
+// Fixed PQMF bank (pqmf.py:15-75: taps 62, cutoff 0.15, Kaiser beta 9), factorised:
+//   4 h_k[j] = PQMF_G[j] * PQMF_C[k][j mod 8],  PQMF_C[k][q] = cos((2k+1)(pi/8)(q - 30.5) - (-1)^k pi/4),
+//   PQMF_G[j] = 8 p[j] (-1)^(j/8).  Generated in float64 by scripts/gen_pqmf_tables.py, rounded to fp32.
+__device__ constexpr float PQMF_C[32] = {
+    9.807852507e-01f, 9.807852507e-01f, 8.314695954e-01f, 5.555702448e-01f,
+    1.950903237e-01f, -1.950903237e-01f, -5.555702448e-01f, -8.314695954e-01f,
+    -8.314695954e-01f, -8.314695954e-01f, 1.950903237e-01f, 9.807852507e-01f,
+    5.555702448e-01f, -5.555702448e-01f, -9.807852507e-01f, -1.950903237e-01f,
+    -5.555702448e-01f, -5.555702448e-01f, 9.807852507e-01f, -1.950903237e-01f,
+    -8.314695954e-01f, 8.314695954e-01f, 1.950903237e-01f, -9.807852507e-01f,
+    1.950903237e-01f, 1.950903237e-01f, -5.555702448e-01f, 8.314695954e-01f,
+    -9.807852507e-01f, 9.807852507e-01f, -8.314695954e-01f, 5.555702448e-01f,
+};
+__device__ constexpr float PQMF_G[64] = {
+    6.692762690e-05f, 2.144142782e-04f, 4.045689129e-04f, 4.907859839e-04f,
+    2.202252799e-04f, -6.902719615e-04f, -2.394147683e-03f, -4.707115702e-03f,
+    6.936517078e-03f, 7.863246836e-03f, 5.977601744e-03f, -6.432701142e-18f,
+    -1.040009875e-02f, -2.390390635e-02f, -3.716831654e-02f, -4.507908970e-02f,
+    4.180690646e-02f, 2.259947546e-02f, -1.405207906e-02f, -6.448587775e-02f,
+    -1.188977659e-01f, -1.619237214e-01f, -1.750242710e-01f, -1.404098570e-01f,
+    4.571796954e-02f, -1.117221490e-01f, -3.222790956e-01f, -5.640172958e-01f,
+    -8.056510091e-01f, -1.012026548e+00f, -1.150984049e+00f, -1.200000048e+00f,
+    1.150984049e+00f, 1.012026548e+00f, 8.056510091e-01f, 5.640172958e-01f,
+    3.222790956e-01f, 1.117221490e-01f, -4.571796954e-02f, -1.404098570e-01f,
+    1.750242710e-01f, 1.619237214e-01f, 1.188977659e-01f, 6.448587775e-02f,
+    1.405207906e-02f, -2.259947546e-02f, -4.180690646e-02f, -4.507908970e-02f,
+    3.716831654e-02f, 2.390390635e-02f, 1.040009875e-02f, 6.432701142e-18f,
+    -5.977601744e-03f, -7.863246836e-03f, -6.936517078e-03f, -4.707115702e-03f,
+    2.394147683e-03f, 6.902719615e-04f, -2.202252799e-04f, -4.907859839e-04f,
+    -4.045689129e-04f, -2.144142782e-04f, -6.692762690e-05f, 0.000000000e+00f,
+};
+
 template <bool FAST>
 __device__ __forceinline__ void polar(float xm, float xp, float& mag, float& ph, float& re,
                                       float& im, bool need_im) {
@@ -79,15 +111,61 @@ __device__ __forceinline__ void polar(float xm, float xp, float& mag, float& ph,
   }
 }
 
+// 16-point real inverse DFT of a one-sided spectrum (Im of DC / Nyquist ignored, as c2r
+// does), times hann(16)/16.  Packed real-IFFT: with A_k = X_k + conj(X_{8-k}),
+// D_k = X_k - conj(X_{8-k}), Z_k = A_k + j W^k D_k (W = e^{j 2 pi/16}, k < 8) one has
+// x[2n] + j x[2n+1] = (1/16) sum_k Z_k e^{j 2 pi k n / 8}; Z_{8-k} = conj(A_k - j W^k D_k).
+// The 8-point complex inverse transform is two radix-4 butterflies + one radix-2 stage:
+// ~110 flops instead of the 16 x 16 matrix form.
+struct cpx { float r, i; };
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.r - b.r, a.i - b.i}; }
+__device__ __forceinline__ void idft4(cpx y0, cpx y1, cpx y2, cpx y3, cpx o[4]) {
+  const cpx t0 = cadd(y0, y2), t1 = csub(y0, y2), t2 = cadd(y1, y3), t3 = csub(y1, y3);
+  o[0] = cadd(t0, t2);
+  o[2] = csub(t0, t2);
+  o[1] = {t1.r - t3.i, t1.i + t3.r};      // t1 + j t3
+  o[3] = {t1.r + t3.i, t1.i - t3.r};      // t1 - j t3
+}
+__device__ __forceinline__ void irfft16_hann(const float* re, const float* im, float* out) {
+  cpx Z[8];
+  Z[0] = {re[0] + re[8], re[0] - re[8]};
+  Z[4] = {2.f * re[4], -2.f * im[4]};
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float Ar = re[k] + re[8 - k], Ai = im[k] - im[8 - k];
+    const float Dr = re[k] - re[8 - k], Di = im[k] + im[8 - k];
+    const float Br = -SIN16[k] * Dr - COS16[k] * Di;
+    const float Bi = COS16[k] * Dr - SIN16[k] * Di;
+    Z[k] = {Ar + Br, Ai + Bi};
+    Z[8 - k] = {Ar - Br, Bi - Ai};
+  }
+  cpx E[4], O[4];
+  idft4(Z[0], Z[2], Z[4], Z[6], E);
+  idft4(Z[1], Z[3], Z[5], Z[7], O);
+  constexpr float r = 0.70710678118654752f;
+  const cpx T0 = O[0];
+  const cpx T1 = {(O[1].r - O[1].i) * r, (O[1].r + O[1].i) * r};
+  const cpx T2 = {-O[2].i, O[2].r};
+  const cpx T3 = {(-O[3].r - O[3].i) * r, (O[3].r - O[3].i) * r};
+  const cpx T[4] = {T0, T1, T2, T3};
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const cpx a = cadd(E[n], T[n]), b = csub(E[n], T[n]);
+    out[2 * n] = a.r * (HANN16[2 * n] * (1.f / 16.f));
+    out[2 * n + 1] = a.i * (HANN16[2 * n + 1] * (1.f / 16.f));
+    out[2 * n + 8] = b.r * (HANN16[2 * n + 8] * (1.f / 16.f));
+    out[2 * n + 9] = b.i * (HANN16[2 * n + 9] * (1.f / 16.f));
+  }
+}
+
 }  // namespace
 
-// Table `filt` (device, 320 floats):
-//   [0, 256)    trainable-bank polyphase taps  t[band][p][i] = 4 h[band][3 - p + 4 i]
-//   [256, 288)  fixed bank: c[k][q] = cos(theta_k(q)), k < 4, q < 8
-//   [288, 352)  fixed bank: g[j] = 8 p[j] (-1)^(j/8), j < 63 (g[63] = 0)
+// `taps` (device, 256 floats, only read by the trainable-bank variant):
+//   t[band][p][i] = 4 h[band][3 - p + 4 i]   (x4 up-sampling gain folded in; 0 where the tap is > 62)
 template <int TM, int NTHREADS, bool FIXED, bool FAST>
-__global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, int tiles_per_utt,
-                                                              int total_tiles) {
+__global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, const float* __restrict__ taps,
+                                                              int tiles_per_utt, int total_tiles) {
   constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
   constexpr int NFS = ((NF + 31) / 32) * 32 + 8;   // LDS frame stride, == 8 (mod 32): conflict-free phase B
   constexpr int YL = TM + 16;             // sub-band samples incl. PQMF halo
@@ -119,10 +197,12 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
     const int f = f_lo + fl;
     float out[16];
     if (f >= 0 && f < F) {
-      const float* xp = a.x_post + ((int64_t)b * 72 + band * 18) * F + f;
+      // uniform 64-bit base + 32-bit lane offset (launch_istft_pqmf checks the tensor is < 4 GiB)
+      const float* xb = a.x_post + (int64_t)b * 72 * F;
+      const unsigned int off = (unsigned int)(band * 18 * F + f);
       float xin[18];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) xin[k] = xp[(int64_t)k * F];
+      for (int k = 0; k < 18; ++k) xin[k] = xb[off + (unsigned int)(k * F)];
       float re[9], im[9];
       // frame f is owned (for the spec/phase outputs) by the tile holding sample 4f
       const bool own = (4 * f >= m0 && 4 * f < m0 + TM) || (f == F - 1 && m0 + TM >= M);
@@ -135,19 +215,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
           if (a.phase) a.phase[(((int64_t)b * 4 + band) * 9 + k) * F + f] = ph;
         }
       }
-      // x[n] = E[n] + O[n], x[n+8] = E[n] - O[n]  (even / odd bins)
-#pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        float e = re[0] + ((n & 1) ? -re[8] : re[8]);
-        float o = 0.f;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-          const float term = 2.f * (re[k] * COS16[(k * n) & 15] - im[k] * SIN16[(k * n) & 15]);
-          if (k & 1) o += term; else e += term;
-        }
-        out[n] = (e + o) * (1.f / 16.f) * HANN16[n];
-        out[n + 8] = (e - o) * (1.f / 16.f) * HANN16[n + 8];
-      }
+      irfft16_hann(re, im, out);
     } else {
 #pragma unroll
       for (int n = 0; n < 16; ++n) out[n] = 0.f;
@@ -177,13 +245,14 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
           env += (f >= 0 && f < F) ? WSQ16[12 - 4 * g + r] : 0.f;
         }
       }
+      const float renv = 1.f / env;          // one division per lane (torch.istft divides per sample)
 #pragma unroll
       for (int band = 0; band < 4; ++band) {
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g)      // frame f'-1+g contributes its sample n = 12 - 4g + r
           s += fr[(band * 16 + 12 - 4 * g + r) * NFS + q + g];
-        y[band] = s / env;
+        y[band] = s * renv;
       }
       if (a.o_mb && u >= 8 && u < TM + 8) {          // owned samples m0 .. m0+TM-1
         if (!a.multistream) {
@@ -198,10 +267,10 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
       }
     }
     if constexpr (FIXED) {
-      const float* c = a.filt + 256;
 #pragma unroll
       for (int qq = 0; qq < 8; ++qq)
-        rowv[qq] = c[qq] * y[0] + c[8 + qq] * y[1] + c[16 + qq] * y[2] + c[24 + qq] * y[3];
+        rowv[qq] = PQMF_C[qq] * y[0] + PQMF_C[8 + qq] * y[1] + PQMF_C[16 + qq] * y[2] +
+                   PQMF_C[24 + qq] * y[3];
     } else {
 #pragma unroll
       for (int band = 0; band < 4; ++band) rowv[band] = y[band];
@@ -220,20 +289,19 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
     if (m < M) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (FIXED) {
-        const float* g = a.filt + 288;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int j = 3 - p + 4 * i;           // tap index; y index m - 7 + i
-            if (j <= 62) acc[p] = fmaf(g[j], prod[(j & 7) * YL + tid + 1 + i], acc[p]);
+            if (j <= 62) acc[p] = fmaf(PQMF_G[j], prod[(j & 7) * YL + tid + 1 + i], acc[p]);
           }
         }
       } else {
 #pragma unroll
         for (int band = 0; band < 4; ++band) {
           const float* yb = &prod[band * YL + tid + 1];        // y[m - 7 + i]
-          const float* hb = a.filt + band * 64;
+          const float* hb = taps + band * 64;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float yv = yb[i];
@@ -255,11 +323,11 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
   const int total = tiles_per_utt * a.B;
   const dim3 grid(total), block(NT);
   if (a.fixed_bank) {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, false>), grid, block, 0, s, a, tiles_per_utt, total);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, true>), grid, block, 0, s, a, tiles_per_utt, total);
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
   } else {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, false>), grid, block, 0, s, a, tiles_per_utt, total);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, true>), grid, block, 0, s, a, tiles_per_utt, total);
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
   }
 }
 
