@@ -26,15 +26,14 @@ namespace mbv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CONV_BN = 128;
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int WM, int CK>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
-  constexpr int BM = 64 * WM;
-  constexpr int BN = CONV_BN;
+template <int WM, int WN, int CK>
+__global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
+  constexpr int BM = 64 * WM;      // 2 waves x WM tiles of 32 rows
+  constexpr int BN = 64 * WN;      // 2 waves x WN tiles of 32 columns
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -52,11 +51,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
   float* Xs = lds;                                    // [CK][XS]
   float* Ws = lds + ((CK * XS + 3) & ~3);             // [K][CK][BM]
 
-  f32x16 acc[WM][2];
+  f32x16 acc[WM][WN];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -104,32 +103,31 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
     if (nact == WM) {
       for (int tap = 0; tap < a.K; ++tap) {
         const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
-        const float* xrow = Xs + hl * XS + wn * 64 + l31 + tap * a.dil;
+        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
 #pragma unroll
         for (int c2 = 0; c2 < CK / 2; ++c2) {
-          float av[WM], bv[2];
+          float av[WM], bv[WN];
 #pragma unroll
           for (int i = 0; i < WM; ++i) av[i] = wrow[c2 * 2 * BM + i * 32];
-          bv[0] = xrow[c2 * 2 * XS];
-          bv[1] = xrow[c2 * 2 * XS + 32];
 #pragma unroll
-          for (int i = 0; i < WM; ++i) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[0], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[1], acc[i][1], 0, 0, 0);
-          }
+          for (int j = 0; j < WN; ++j) bv[j] = xrow[c2 * 2 * XS + j * 32];
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
       }
     } else if (nact == 1) {   // only reachable with WM == 2
       for (int tap = 0; tap < a.K; ++tap) {
         const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
-        const float* xrow = Xs + hl * XS + wn * 64 + l31 + tap * a.dil;
+        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
 #pragma unroll
         for (int c2 = 0; c2 < CK / 2; ++c2) {
           const float av = wrow[c2 * 2 * BM];
-          const float b0 = xrow[c2 * 2 * XS];
-          const float b1 = xrow[c2 * 2 * XS + 32];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[0][1], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xrow[c2 * 2 * XS + j * 32], acc[0][j], 0, 0, 0);
         }
       }
     }
@@ -153,8 +151,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
           float bs = a.bias ? a.bias[a.gate_half + c] : 0.f;
           if (gc) { bt += gc[c]; bs += gc[a.gate_half + c]; }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int t = t0 + wn * 64 + j * 32 + l31;
+          for (int j = 0; j < WN; ++j) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
             if (t < T) {
               const float vt = tanhf(acc[0][j][r] + bt);
               const float vs = sigmoidf_(acc[1][j][r] + bs);
@@ -176,8 +174,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
       if (row >= a.M) continue;
       const float bias = a.bias ? a.bias[row] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int t = t0 + wn * 64 + j * 32 + l31;
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + wn * 32 * WN + j * 32 + l31;
         if (t >= T) continue;
         float v = acc[i][j][r] + bias;
         const float mask = t < len_out ? 1.f : 0.f;
@@ -220,28 +218,33 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int WM, int CK>
+template <int WM, int WN, int CK>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
-  constexpr int BM = 64 * WM;
-  const int XL = CONV_BN + (a.K - 1) * a.dil;
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  const int XL = BN + (a.K - 1) * a.dil;
   const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM;
-  const size_t lds_bytes = lds_floats * sizeof(float);
-  dim3 grid((a.T + CONV_BN - 1) / CONV_BN, (a.M + BM - 1) / BM, a.B);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, CK>), grid, dim3(256), lds_bytes, s, a);
+  dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK>), grid, dim3(256), lds_floats * sizeof(float), s, a);
+}
+
+template <int WM, int WN>
+static void launch_ck(const ConvArgs& a, hipStream_t s) {
+  // chunk of input channels staged per LDS pass: keep K*CK around 64-96 rows of weights
+  const int ck = a.K >= 7 ? 8 : (a.K >= 2 ? 16 : 32);
+  if (ck == 8) launch_one<WM, WN, 8>(a, s);
+  else if (ck == 16) launch_one<WM, WN, 16>(a, s);
+  else launch_one<WM, WN, 32>(a, s);
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
-  const bool wide = a.M > 64 || a.epi == EPI_GATE;
-  // chunk of input channels staged per LDS pass: keep K*CK around 64-96 rows of weights
-  const int ck = a.K >= 7 ? 8 : (a.K >= 2 ? 16 : 32);
-  if (wide) {
-    if (ck == 8) launch_one<2, 8>(a, s);
-    else if (ck == 16) launch_one<2, 16>(a, s);
-    else launch_one<2, 32>(a, s);
+  const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
+  // long sequences (flow / decoder): 64 x 128 outputs per wave halves the weight staging per FLOP
+  const bool wide_n = wide_m && a.T >= 1024;
+  if (wide_m) {
+    if (wide_n) launch_ck<2, 4>(a, s);
+    else launch_ck<2, 2>(a, s);
   } else {
-    if (ck == 8) launch_one<1, 8>(a, s);
-    else if (ck == 16) launch_one<1, 16>(a, s);
-    else launch_one<1, 32>(a, s);
+    launch_ck<1, 2>(a, s);
   }
 }
 
