@@ -101,22 +101,40 @@ __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const
     __syncthreads();
     // ---- MFMA over taps x channel pairs ---------------------------------
     if (nact == WM) {
-      for (int tap = 0; tap < a.K; ++tap) {
-        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
-        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
+      // Flattened (tap, channel-pair) loop, operands double-buffered in registers: the
+      // ds_reads of step s+1 are in flight while the MFMAs of step s occupy the pipe.
+      constexpr int HP = CK / 2;                       // channel pairs per chunk
+      const int nsteps = a.K * HP;                     // even (HP is even)
+      const float* wbase = Ws + hl * BM + wm * 32 * WM + l31;
+      const float* xbase = Xs + hl * XS + wn * 32 * WN + l31;
+      auto load_ab = [&](int st, float (&av)[WM], float (&bv)[WN]) {
+        const int tap = st / HP, c2 = st % HP;
+        const float* wp = wbase + st * (2 * BM);       // row tap*CK + 2*c2 == 2*st
+        const float* xp = xbase + c2 * (2 * XS) + tap * a.dil;
 #pragma unroll
-        for (int c2 = 0; c2 < CK / 2; ++c2) {
-          float av[WM], bv[WN];
+        for (int i = 0; i < WM; ++i) av[i] = wp[i * 32];
 #pragma unroll
-          for (int i = 0; i < WM; ++i) av[i] = wrow[c2 * 2 * BM + i * 32];
+        for (int j = 0; j < WN; ++j) bv[j] = xp[j * 32];
+      };
+      auto mma = [&](const float (&av)[WM], const float (&bv)[WN]) {
 #pragma unroll
-          for (int j = 0; j < WN; ++j) bv[j] = xrow[c2 * 2 * XS + j * 32];
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      };
+      float a0[WM], b0[WN], a1[WM], b1[WN];
+      load_ab(0, a0, b0);
+      for (int st = 0; st < nsteps; st += 2) {
+        // sched_barrier: keep hipcc from sinking the prefetch back behind the MFMAs
+        load_ab(st + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_ab(st + 2, a0, b0);     // last iteration reads one step past the slab: padded, unused
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if (nact == 1) {   // only reachable with WM == 2
       for (int tap = 0; tap < a.K; ++tap) {
@@ -222,7 +240,8 @@ template <int WM, int WN, int CK>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   const int XL = BN + (a.K - 1) * a.dil;
-  const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM;
+  // + 2 rows of padding: the operand prefetch runs one K-step past the weight slab
+  const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM + 2 * BM;
   dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
   hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK>), grid, dim3(256), lds_floats * sizeof(float), s, a);
 }
