@@ -21,6 +21,7 @@
 // input window [CK][128 + halo] and the weight slab [K][CK][BM] are staged in
 // LDS once and reused by all taps.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mbv {
 
@@ -30,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int WM, int WN, int CK>
+template <int WM, int WN, int CK, bool PIPE>
 __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
   constexpr int BM = 64 * WM;      // 2 waves x WM tiles of 32 rows
   constexpr int BN = 64 * WN;      // 2 waves x WN tiles of 32 columns
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const
     }
     __syncthreads();
     // ---- MFMA over taps x channel pairs ---------------------------------
-    if (nact == WM) {
+    if (nact == WM && PIPE) {
       // Flattened (tap, channel-pair) loop, operands double-buffered in registers: the
       // ds_reads of step s+1 are in flight while the MFMAs of step s occupy the pipe.
       constexpr int HP = CK / 2;                       // channel pairs per chunk
@@ -135,6 +136,24 @@ __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (nact == WM) {
+      for (int tap = 0; tap < a.K; ++tap) {
+        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
+        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
+#pragma unroll
+        for (int c2 = 0; c2 < CK / 2; ++c2) {
+          float av[WM], bv[WN];
+#pragma unroll
+          for (int i = 0; i < WM; ++i) av[i] = wrow[c2 * 2 * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < WN; ++j) bv[j] = xrow[c2 * 2 * XS + j * 32];
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
       }
     } else if (nact == 1) {   // only reachable with WM == 2
       for (int tap = 0; tap < a.K; ++tap) {
@@ -243,7 +262,9 @@ static void launch_one(const ConvArgs& a, hipStream_t s) {
   // + 2 rows of padding: the operand prefetch runs one K-step past the weight slab
   const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM + 2 * BM;
   dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK>), grid, dim3(256), lds_floats * sizeof(float), s, a);
+  static const int pipe = [] { const char* e = getenv("MBV_CONV_PIPE"); return e ? atoi(e) : 0; }();
+  if (pipe) hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, true>), grid, dim3(256), lds_floats * sizeof(float), s, a);
+  else hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, false>), grid, dim3(256), lds_floats * sizeof(float), s, a);
 }
 
 template <int WM, int WN>
@@ -258,7 +279,8 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
   // long sequences (flow / decoder): 64 x 128 outputs per wave halves the weight staging per FLOP
-  const bool wide_n = wide_m && a.T >= 1024;
+  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 1; }();
+  const bool wide_n = widen && wide_m && a.T >= 1024;
   if (wide_m) {
     if (wide_n) launch_ck<2, 4>(a, s);
     else launch_ck<2, 2>(a, s);
