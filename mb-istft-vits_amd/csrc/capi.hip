@@ -672,9 +672,14 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   if (cfg->decoder != MBV_DEC_MULTIBAND && cfg->decoder != MBV_DEC_MULTISTREAM) return bad("unknown decoder");
   if (cfg->n_speakers > 1 && cfg->gin_channels <= 0) return bad("n_speakers > 1 needs gin_channels > 0");
   for (int j = 0; j < 3; ++j)
-    if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0 ||
-        cfg->resblock_kernel_sizes[j] > 15)
-      return bad("resblock kernel sizes must be odd and <= 15");
+    if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0)
+      return bad("resblock kernel sizes must be odd");
+  for (int j = 0; j < 3; ++j)
+    for (int q = 0; q < 3; ++q)
+      if (cfg->resblock_dilations[j][q] < 1 ||
+          !conv1d_supported(cfg->resblock_kernel_sizes[j], cfg->resblock_dilations[j][q]))
+        return bad("resblock kernel size / dilation outside the built range (k <= 11, (k-1)*d <= 72)");
+  if (!conv1d_supported(cfg->kernel_size, 1)) return bad("FFN kernel_size outside the built range");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return bad("no HIP device visible: this library has no CPU fallback");
@@ -1039,6 +1044,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
                   int B, int Cin, int Cout, int T, int K, int dilation, float in_slope, void* stream) {
   if (!m) return 1;
   if (Cin % 32) return m->fail("mbv_op_conv1d: Cin must be a multiple of 32");
+  if (!conv1d_supported(K, dilation)) return m->fail("mbv_op_conv1d: K <= 11 and (K-1)*dilation <= 72 required");
   HIPCHK(m, hipSetDevice(m->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   const int Mpad = (int)align_up(Cout, 128);

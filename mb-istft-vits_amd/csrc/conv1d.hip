@@ -21,18 +21,20 @@
 // input window [CK][128 + halo] and the weight slab [K][CK][BM] are staged in
 // LDS once and reused by all taps.
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace mbv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 template <int WM, int WN, int CK, bool PIPE>
-__global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   constexpr int BM = 64 * WM;      // 2 waves x WM tiles of 32 rows
   constexpr int BN = 64 * WN;      // 2 waves x WN tiles of 32 columns
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -69,37 +71,80 @@ __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const
   const int len_in = a.in_lens ? a.in_lens[b] : 0x7fffffff;
   const int tin_eff = a.reflect1 ? a.Tin + 1 : a.Tin;  // length of the (virtually padded) input
 
-  for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
-    __syncthreads();
-    // ---- stage the activated input window ------------------------------
-    for (int r = wave; r < CK; r += 4) {
-      const int ci = ci0 + r;
-      const float* xr = xb + (int64_t)ci * a.x_rstride;
-      const float cadd = a.chan_add ? a.chan_add[b * a.Cin + ci] : 0.f;
-      for (int c = lane; c < XL; c += 64) {
-        int gi = t0 - a.pad_left + c;
-        float v = 0.f;
+  // ---- async-stage split (global -> registers -> LDS) --------------------------
+  // All global loads of chunk c+1 (weight slab + raw input window) are issued into
+  // registers BEFORE the MFMA loop of chunk c and committed to LDS after it, so their
+  // L2/HBM latency hides under the matrix work instead of serialising in front of it.
+  constexpr int Q = BM / 4;                                   // float4 per weight row
+  constexpr int RPI = 256 / Q;                                // weight rows the block copies per pass
+  constexpr int HALO_MAX = CK == 8 ? 72 : (CK == 16 ? 24 : 0);
+  constexpr int NX = (CK * (BN + HALO_MAX) + 255) / 256;      // input floats per thread
+  constexpr int KMAX = CK == 8 ? 11 : (CK == 16 ? 5 : 1);
+  constexpr int NW = (KMAX * CK * Q + 255) / 256;             // weight float4 per thread
+  static_assert(RPI % CK == 0 || CK % RPI == 0, "weight-row decomposition");
+  f32x4 wreg[NW];
+  float xreg[NX];
+  const int totalW = a.K * CK * Q;
+
+  // Weight slab: thread (row_0 = tid / Q, q = tid % Q) copies rows row_0 + u * RPI.  Row =
+  // tap * CK + c, so pass u differs from pass 0 by a WAVE-UNIFORM element offset: one 64-bit
+  // lane base, scalar offsets per pass (saddr-form loads, no per-pass address VGPRs).
+  const int wq = tid % Q, wrow_0 = tid / Q;
+  const int wtap_0 = RPI >= CK ? wrow_0 / CK : 0;             // per-lane tap of pass 0
+  const int wc_0 = RPI >= CK ? wrow_0 % CK : wrow_0;          // per-lane channel of pass 0
+  const float* wlane = a.w + ((int64_t)wtap_0 * a.Cin + wc_0) * a.Mpad + m0 + 4 * wq;
+  const int64_t tap_stride = (int64_t)a.Cin * a.Mpad;
+
+  // Input window: element e = tid + 256 u of the [CK][XL] tile -> (row, col).  The global
+  // offset inside a chunk (row * x_rstride + gi) is the same for every chunk: computed once,
+  // -1 marks zero padding (outside the signal, or masked by in_lens).
+  int xoff[NX];
+  {
+    int row = tid / XL, col = tid - row * XL;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      int off = -1;
+      if (row < CK) {
+        int gi = t0 - a.pad_left + col;
         if (gi >= 0 && gi < tin_eff) {
           if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;
-          v = lrelu(xr[gi] + cadd, a.in_slope);
-          if (gi >= len_in) v = 0.f;
+          if (gi < len_in) off = row * a.x_rstride + gi;
         }
-        Xs[r * XS + c] = v;
       }
+      xoff[u] = off;
+      col += 256;
+      if (col >= XL) { col -= XL; ++row; }
+      if (col >= XL) { col -= XL; ++row; }
     }
-    // ---- stage the weight slab -----------------------------------------
-    {
-      constexpr int Q = BM / 4;
-      const int total = a.K * CK * Q;
-      for (int e = tid; e < total; e += 256) {
-        const int row = e / Q, q = e % Q;
-        const int tap = row / CK, c = row % CK;
-        const float4* src =
-            reinterpret_cast<const float4*>(a.w + ((int64_t)tap * a.Cin + ci0 + c) * a.Mpad + m0) + q;
-        reinterpret_cast<float4*>(Ws + row * BM)[q] = *src;
+  }
+
+  // One loop body, entered first with ci0 = -CK: issue(chunk 0) / skip compute / commit(chunk 0).
+  for (int ci0 = -CK; ci0 < a.Cin; ci0 += CK) {
+    const bool more = ci0 + CK < a.Cin;
+    const int cn = ci0 + CK;                                  // chunk being prefetched
+    if (more) {
+      // ---- issue: weight slab [K][CK][BM] and the raw input window -> registers
+      const float* wchunk = wlane + (int64_t)cn * a.Mpad;
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        int64_t off;
+        if constexpr (RPI >= CK) {
+          int tap = wtap_0 + u * (RPI / CK);                   // per-lane, clamped to stay in the slab
+          tap = tap < a.K ? tap : a.K - 1;
+          off = (int64_t)(tap - wtap_0) * tap_stride;
+        } else {
+          constexpr int PPT = CK / RPI;                        // passes per tap
+          int tap = u / PPT;                                   // wave-uniform
+          tap = tap < a.K ? tap : a.K - 1;
+          off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad;
+        }
+        wreg[u] = *reinterpret_cast<const f32x4*>(wchunk + off);
       }
+      const float* xchunk = xb + (int64_t)cn * a.x_rstride;
+#pragma unroll
+      for (int u = 0; u < NX; ++u) xreg[u] = xoff[u] >= 0 ? xchunk[(unsigned)xoff[u]] : 0.f;
     }
-    __syncthreads();
+    if (ci0 >= 0) {
     // ---- MFMA over taps x channel pairs ---------------------------------
     if (nact == WM && PIPE) {
       // Flattened (tap, channel-pair) loop, operands double-buffered in registers: the
@@ -167,6 +212,32 @@ __global__ __launch_bounds__(256, WN >= 4 ? 2 : 3) void conv1d_mfma_kernel(const
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xrow[c2 * 2 * XS + j * 32], acc[0][j], 0, 0, 0);
         }
       }
+    }
+    }   // ci0 >= 0
+    if (more) {
+      __syncthreads();            // every wave is done reading the previous chunk from LDS
+      // ---- commit: registers -> LDS, activation / conditioning applied on the way
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int e = tid + 256 * u;
+        if (e < totalW) reinterpret_cast<f32x4*>(Ws)[e] = wreg[u];   // Ws[row][q] is linear in e
+      }
+      int row = tid / XL, col = tid - row * XL;
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        if (row < CK) {
+          float v = 0.f;
+          if (xoff[u] >= 0) {
+            const float cadd = a.chan_add ? a.chan_add[b * a.Cin + cn + row] : 0.f;
+            v = lrelu(xreg[u] + cadd, a.in_slope);
+          }
+          Xs[row * XS + col] = v;
+        }
+        col += 256;
+        if (col >= XL) { col -= XL; ++row; }
+        if (col >= XL) { col -= XL; ++row; }
+      }
+      __syncthreads();
     }
   }
 
@@ -267,13 +338,22 @@ static void launch_one(const ConvArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, false>), grid, dim3(256), lds_floats * sizeof(float), s, a);
 }
 
+bool conv1d_supported(int K, int dil) {
+  return K >= 1 && K <= 11 && (K - 1) * dil <= 72;
+}
+
 template <int WM, int WN>
 static void launch_ck(const ConvArgs& a, hipStream_t s) {
-  // chunk of input channels staged per LDS pass: keep K*CK around 64-96 rows of weights
-  const int ck = a.K >= 7 ? 8 : (a.K >= 2 ? 16 : 32);
-  if (ck == 8) launch_one<WM, WN, 8>(a, s);
-  else if (ck == 16) launch_one<WM, WN, 16>(a, s);
-  else launch_one<WM, WN, 32>(a, s);
+  // chunk of input channels staged per LDS pass (register budget of the async stage:
+  // CK=8: K <= 11, halo <= 72; CK=16: K <= 5, halo <= 24; CK=32: K == 1)
+  const int halo = (a.K - 1) * a.dil;
+  if (!conv1d_supported(a.K, a.dil)) {
+    fprintf(stderr, "mbv: conv1d kernel size %d / dilation %d outside the built range\n", a.K, a.dil);
+    abort();
+  }
+  if (a.K == 1) launch_one<WM, WN, 32>(a, s);
+  else if (a.K <= 5 && halo <= 24) launch_one<WM, WN, 16>(a, s);
+  else launch_one<WM, WN, 8>(a, s);
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {

@@ -59,6 +59,7 @@ struct ConvArgs {
   int B;
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
+bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
 
 // ---------------------------------------------------------------- ConvTranspose1d k=16 s=4 p=6 (MFMA)
 // Packed: Wt[r][j][Cin][Mpad] with Wt[r][j][ci][co] = W[ci][co][(r+2)%4 + 4j]
