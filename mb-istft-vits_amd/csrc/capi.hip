@@ -218,6 +218,12 @@ void build_expected(mbv_model* m) {
 }
 
 // ------------------------------------------------------------------ packing
+// k-interleaved weight order the conv kernel copies verbatim into LDS (conv1d.hip):
+//   Wp[tap][Cin/8][h = ci & 1][Mpad][s = (ci % 8) / 2]
+inline size_t conv_pack_index(int tap, int ci, int m, int Cin, int Mpad) {
+  return ((((size_t)tap * (Cin / 8) + ci / 8) * 2 + (ci & 1)) * Mpad + m) * 4 + ((ci & 7) >> 1);
+}
+
 struct Packer {
   mbv_model* m;
   std::vector<float>& a;
@@ -269,11 +275,11 @@ struct Packer {
     p.w = alloc((size_t)K * Cin * p.Mpad);
     for (int k = 0; k < K; ++k)
       for (int ci = 0; ci < Cin; ++ci) {
-        float* dst = &a[p.w + ((size_t)k * Cin + ci) * p.Mpad];
         const int sci = cin_map.empty() ? ci : cin_map[ci];
         for (int mrow = 0; mrow < p.M; ++mrow) {
           const int co = rows[mrow];
-          dst[mrow] = co < 0 ? 0.f : w[((size_t)co * Cin + sci) * K + k];
+          a[p.w + conv_pack_index(k, ci, mrow, Cin, p.Mpad)] =
+              co < 0 ? 0.f : w[((size_t)co * Cin + sci) * K + k];
         }
       }
     if (bias) {
@@ -1052,7 +1058,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   for (int k = 0; k < K; ++k)
     for (int ci = 0; ci < Cin; ++ci)
       for (int co = 0; co < Cout; ++co)
-        packed[((size_t)k * Cin + ci) * Mpad + co] = w_host[((size_t)co * Cin + ci) * K + k];
+        packed[conv_pack_index(k, ci, co, Cin, Mpad)] = w_host[((size_t)co * Cin + ci) * K + k];
   float *dw = nullptr, *db = nullptr;
   HIPCHK(m, hipMalloc((void**)&dw, packed.size() * 4));
   HIPCHK(m, hipMemcpy(dw, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));

@@ -3,7 +3,7 @@
 // fp32 VALU, but one VGPR per operand and the VALU left free for the fused
 // prologue / epilogue).
 //
-//   y[b, m, t] = bias[m] + sum_{ci, tap} Wp[tap][ci][m] * act(x[b, ci, t + tap*dil - pad_left])
+//   y[b, m, t] = bias[m] + sum_{ci, tap} W[m][ci][tap] * act(x[b, ci, t + tap*dil - pad_left])
 //
 // covers every dense contraction of the path (reference call sites):
 //   attentions.py:139-146 (q/k/v/o 1x1), attentions.py:278-285 (FFN k3),
@@ -14,12 +14,23 @@
 //   residual add fused on the output), models.py:363-365 (lrelu 0.01 +
 //   ReflectionPad1d((1,0)) + subband_conv_post k7).
 //
-// Tiling (wave64): block = 4 waves as 2(M) x 2(N); each wave owns WM x 2 MFMA
-// tiles of 32x32 (rows = output channels, columns = time, so both operands are
-// read with time / channel on the lane: conflict-free ds_read_b32, coalesced
-// global rows).  K loop: Cin in chunks of CK channels; per chunk the activated
-// input window [CK][128 + halo] and the weight slab [K][CK][BM] are staged in
-// LDS once and reused by all taps.
+// Tiling (wave64): block = 4 waves as 2(M) x 2(N); each wave owns WM x WN MFMA
+// tiles of 32x32 (rows = output channels, columns = time).  K loop: Cin in
+// chunks of CK channels (CK/8 groups of 8); per chunk the activated input window
+// and the weight slab are staged in LDS once and reused by all taps.
+//
+// k-interleaved LDS images ("read wide"): a lane's MFMA operand for K-step s of a
+// group is channel 2s + (lane>>5); both images keep the four K-steps of a group
+// adjacent,
+//     Ws[tap][group][h][m][4]        Xs[group][h][col][4]        (h = channel & 1)
+// so ONE ds_read_b128 per operand tile feeds four MFMAs per accumulator (16 / 32
+// MFMAs per 4 / 6 LDS reads instead of one read per MFMA), conflict-free (lanes
+// are 16 B apart).  The weights are packed in exactly this order on the host
+// (capi.hip pack_conv), so the slab is a linear copy.
+//
+// Staging is an async split (global -> registers -> LDS): all loads of chunk c+1
+// are issued before the MFMA loop of chunk c and committed to LDS after it; the
+// operand reads inside the loop are double-buffered in registers one group ahead.
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -29,14 +40,14 @@ namespace mbv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int WM, int WN, int CK, bool PIPE>
+template <int WM, int WN, int CK>
 __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   constexpr int BM = 64 * WM;      // 2 waves x WM tiles of 32 rows
   constexpr int BN = 64 * WN;      // 2 waves x WN tiles of 32 columns
+  constexpr int G = CK / 8;        // channel groups (4 K-steps each) per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -49,10 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   const int t0 = blockIdx.x * BN;
 
   const int halo = (a.K - 1) * a.dil;
-  const int XL = BN + halo;
-  const int XS = XL;                                  // row stride in floats
-  float* Xs = lds;                                    // [CK][XS]
-  float* Ws = lds + ((CK * XS + 3) & ~3);             // [K][CK][BM]
+  const int XL = BN + halo;                            // staged columns
+  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);     // [G][2][XL]   (x4 K-steps)
+  f32x4* const Ws = Xs + G * 2 * XL;                   // [K][G][2][BM] (x4 K-steps)
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -71,171 +81,165 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   const int len_in = a.in_lens ? a.in_lens[b] : 0x7fffffff;
   const int tin_eff = a.reflect1 ? a.Tin + 1 : a.Tin;  // length of the (virtually padded) input
 
-  // ---- async-stage split (global -> registers -> LDS) --------------------------
-  // All global loads of chunk c+1 (weight slab + raw input window) are issued into
-  // registers BEFORE the MFMA loop of chunk c and committed to LDS after it, so their
-  // L2/HBM latency hides under the matrix work instead of serialising in front of it.
-  constexpr int Q = BM / 4;                                   // float4 per weight row
-  constexpr int RPI = 256 / Q;                                // weight rows the block copies per pass
+  // ---- async-stage bookkeeping ------------------------------------------------
   constexpr int HALO_MAX = CK == 8 ? 72 : (CK == 16 ? 24 : 0);
-  constexpr int NX = (CK * (BN + HALO_MAX) + 255) / 256;      // input floats per thread
   constexpr int KMAX = CK == 8 ? 11 : (CK == 16 ? 5 : 1);
-  constexpr int NW = (KMAX * CK * Q + 255) / 256;             // weight float4 per thread
-  static_assert(RPI % CK == 0 || CK % RPI == 0, "weight-row decomposition");
+  constexpr int NXP = (G * 2 * (BN + HALO_MAX) + 255) / 256;   // (group, h, col) items per thread
+  constexpr int NW = (KMAX * G * 2 * BM + 255) / 256;          // weight float4 per thread
+  constexpr int RPI = 256 / BM;                                // weight rows [BM x f32x4] per pass
+  constexpr int ROWS_PER_TAP = 2 * G;
+  static_assert(RPI % ROWS_PER_TAP == 0 || ROWS_PER_TAP % RPI == 0, "weight-row decomposition");
   f32x4 wreg[NW];
-  float xreg[NX];
-  const int totalW = a.K * CK * Q;
+  f32x4 xreg[NXP];
+  const int totalW = a.K * ROWS_PER_TAP * BM;                  // float4 in the slab
 
-  // Weight slab: thread (row_0 = tid / Q, q = tid % Q) copies rows row_0 + u * RPI.  Row =
-  // tap * CK + c, so pass u differs from pass 0 by a WAVE-UNIFORM element offset: one 64-bit
-  // lane base, scalar offsets per pass (saddr-form loads, no per-pass address VGPRs).
-  const int wq = tid % Q, wrow_0 = tid / Q;
-  const int wtap_0 = RPI >= CK ? wrow_0 / CK : 0;             // per-lane tap of pass 0
-  const int wc_0 = RPI >= CK ? wrow_0 % CK : wrow_0;          // per-lane channel of pass 0
-  const float* wlane = a.w + ((int64_t)wtap_0 * a.Cin + wc_0) * a.Mpad + m0 + 4 * wq;
-  const int64_t tap_stride = (int64_t)a.Cin * a.Mpad;
+  // Weight slab: global order == LDS order ([tap][Cin/8][2][Mpad][4] vs [tap][G][2][BM][4]);
+  // thread copies float4 (row R_0 + u*RPI, column wq).  Pass u differs from pass 0 by a
+  // wave-uniform element offset (saddr-form loads).
+  const int wq = tid % BM, wR0 = tid / BM;
+  const int wtap0 = RPI >= ROWS_PER_TAP ? wR0 / ROWS_PER_TAP : 0;
+  const int wrem0 = RPI >= ROWS_PER_TAP ? wR0 % ROWS_PER_TAP : wR0;
+  const int64_t tap_stride = (int64_t)(a.Cin / 8) * 2 * a.Mpad * 4;       // floats per tap
+  const float* wlane = a.w + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + m0 + wq) * 4;
 
-  // Input window: element e = tid + 256 u of the [CK][XL] tile -> (row, col).  The global
-  // offset inside a chunk (row * x_rstride + gi) is the same for every chunk: computed once,
-  // -1 marks zero padding (outside the signal, or masked by in_lens).
-  int xoff[NX];
+  // Input window: item e = tid + 256 u -> (P = group*2 + h, col); its four K-steps are the
+  // channels 8 g + h + 2 s.  Offset of s = 0 inside a chunk, -1 = zero padding / masked.
+  int xoff[NXP];
   {
-    int row = tid / XL, col = tid - row * XL;
+    int P = tid / XL, col = tid - P * XL;
 #pragma unroll
-    for (int u = 0; u < NX; ++u) {
+    for (int u = 0; u < NXP; ++u) {
       int off = -1;
-      if (row < CK) {
+      if (P < 2 * G) {
         int gi = t0 - a.pad_left + col;
         if (gi >= 0 && gi < tin_eff) {
           if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;
-          if (gi < len_in) off = row * a.x_rstride + gi;
+          if (gi < len_in) off = ((P >> 1) * 8 + (P & 1)) * a.x_rstride + gi;
         }
       }
       xoff[u] = off;
       col += 256;
-      if (col >= XL) { col -= XL; ++row; }
-      if (col >= XL) { col -= XL; ++row; }
+      if (col >= XL) { col -= XL; ++P; }
+      if (col >= XL) { col -= XL; ++P; }
     }
   }
 
   // One loop body, entered first with ci0 = -CK: issue(chunk 0) / skip compute / commit(chunk 0).
   for (int ci0 = -CK; ci0 < a.Cin; ci0 += CK) {
-    const bool more = ci0 + CK < a.Cin;
+    bool more = ci0 + CK < a.Cin;
+    if (a.debug == 1) more = ci0 < 0;                         // timing experiment: stage chunk 0 only
     const int cn = ci0 + CK;                                  // chunk being prefetched
     if (more) {
-      // ---- issue: weight slab [K][CK][BM] and the raw input window -> registers
-      const float* wchunk = wlane + (int64_t)cn * a.Mpad;
+      // ---- issue: weight slab and raw input window -> registers
+      const float* wchunk = wlane + (int64_t)(cn / 8) * 2 * a.Mpad * 4;
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
         int64_t off;
-        if constexpr (RPI >= CK) {
-          int tap = wtap_0 + u * (RPI / CK);                   // per-lane, clamped to stay in the slab
+        if constexpr (RPI >= ROWS_PER_TAP) {
+          int tap = wtap0 + u * (RPI / ROWS_PER_TAP);        // per-lane, clamped to stay in the slab
           tap = tap < a.K ? tap : a.K - 1;
-          off = (int64_t)(tap - wtap_0) * tap_stride;
+          off = (int64_t)(tap - wtap0) * tap_stride;
         } else {
-          constexpr int PPT = CK / RPI;                        // passes per tap
-          int tap = u / PPT;                                   // wave-uniform
+          constexpr int PPT = ROWS_PER_TAP / RPI;            // passes per tap
+          int tap = u / PPT;                                 // wave-uniform
           tap = tap < a.K ? tap : a.K - 1;
-          off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad;
+          off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad * 4;
         }
         wreg[u] = *reinterpret_cast<const f32x4*>(wchunk + off);
       }
       const float* xchunk = xb + (int64_t)cn * a.x_rstride;
+      const unsigned rs2 = 2u * (unsigned)a.x_rstride;
 #pragma unroll
-      for (int u = 0; u < NX; ++u) xreg[u] = xoff[u] >= 0 ? xchunk[(unsigned)xoff[u]] : 0.f;
-    }
-    if (ci0 >= 0) {
-    // ---- MFMA over taps x channel pairs ---------------------------------
-    if (nact == WM && PIPE) {
-      // Flattened (tap, channel-pair) loop, operands double-buffered in registers: the
-      // ds_reads of step s+1 are in flight while the MFMAs of step s occupy the pipe.
-      constexpr int HP = CK / 2;                       // channel pairs per chunk
-      const int nsteps = a.K * HP;                     // even (HP is even)
-      const float* wbase = Ws + hl * BM + wm * 32 * WM + l31;
-      const float* xbase = Xs + hl * XS + wn * 32 * WN + l31;
-      auto load_ab = [&](int st, float (&av)[WM], float (&bv)[WN]) {
-        const int tap = st / HP, c2 = st % HP;
-        const float* wp = wbase + st * (2 * BM);       // row tap*CK + 2*c2 == 2*st
-        const float* xp = xbase + c2 * (2 * XS) + tap * a.dil;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) av[i] = wp[i * 32];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bv[j] = xp[j * 32];
-      };
-      auto mma = [&](const float (&av)[WM], const float (&bv)[WN]) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      };
-      float a0[WM], b0[WN], a1[WM], b1[WN];
-      load_ab(0, a0, b0);
-      for (int st = 0; st < nsteps; st += 2) {
-        // sched_barrier: keep hipcc from sinking the prefetch back behind the MFMAs
-        load_ab(st + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_ab(st + 2, a0, b0);     // last iteration reads one step past the slab: padded, unused
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if (nact == WM) {
-      for (int tap = 0; tap < a.K; ++tap) {
-        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
-        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
-#pragma unroll
-        for (int c2 = 0; c2 < CK / 2; ++c2) {
-          float av[WM], bv[WN];
-#pragma unroll
-          for (int i = 0; i < WM; ++i) av[i] = wrow[c2 * 2 * BM + i * 32];
-#pragma unroll
-          for (int j = 0; j < WN; ++j) bv[j] = xrow[c2 * 2 * XS + j * 32];
-#pragma unroll
-          for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int u = 0; u < NXP; ++u) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (xoff[u] >= 0) {
+          const unsigned o = (unsigned)xoff[u];
+          v[0] = xchunk[o]; v[1] = xchunk[o + rs2]; v[2] = xchunk[o + 2 * rs2]; v[3] = xchunk[o + 3 * rs2];
         }
+        xreg[u] = v;
       }
-    } else if (nact == 1) {   // only reachable with WM == 2
-      for (int tap = 0; tap < a.K; ++tap) {
-        const float* wrow = Ws + (tap * CK + hl) * BM + wm * 32 * WM + l31;
-        const float* xrow = Xs + hl * XS + wn * 32 * WN + l31 + tap * a.dil;
+    }
+
+    if (ci0 >= 0 && a.debug != 3) {
+      // ---- MFMA over (tap, group) steps; each step = 4 K-steps from one b128 per operand tile
+      const int nsteps = a.K * G;
+      const f32x4* wbase = Ws + hl * BM + wm * 32 * WM + l31;       // + step * 2 * BM
+      const f32x4* xbase = Xs + hl * XL + wn * 32 * WN + l31;       // + g * 2 * XL + tap * dil
+      if (nact == WM) {
+        f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
+#define MBV_LOAD_AB(ST, AV, BV)                                                   \
+        {                                                                          \
+          const int st_ = (ST);                                                    \
+          const int tap_ = st_ / G, g_ = st_ % G;                                  \
+          const f32x4* wp_ = wbase + st_ * (2 * BM);                               \
+          const f32x4* xp_ = xbase + g_ * (2 * XL) + tap_ * a.dil;                 \
+          _Pragma("unroll") for (int i = 0; i < WM; ++i) AV[i] = wp_[i * 32];      \
+          _Pragma("unroll") for (int j = 0; j < WN; ++j) BV[j] = xp_[j * 32];      \
+        }
+#define MBV_MMA(AV, BV)                                                            \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                           \
+          _Pragma("unroll") for (int i = 0; i < WM; ++i)                           \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
+        MBV_LOAD_AB(0, a0, b0);
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+          // sched_barrier keeps hipcc from sinking the prefetch back behind the MFMAs
+          MBV_LOAD_AB(st + 1, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          MBV_MMA(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          MBV_LOAD_AB(st + 2, a0, b0);   // the last pass reads one step past the slab (padded, unused)
+          __builtin_amdgcn_sched_barrier(0);
+          MBV_MMA(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st < nsteps) { MBV_MMA(a0, b0); }                // odd step count
+#undef MBV_LOAD_AB
+#undef MBV_MMA
+      } else if (nact == 1) {                                // only reachable with WM == 2
+        for (int st = 0; st < nsteps; ++st) {
+          const int tap = st / G, g = st % G;
+          const f32x4 av = wbase[st * (2 * BM)];
+          const f32x4* xp = xbase + g * (2 * XL) + tap * a.dil;
 #pragma unroll
-        for (int c2 = 0; c2 < CK / 2; ++c2) {
-          const float av = wrow[c2 * 2 * BM];
+          for (int j = 0; j < WN; ++j) {
+            const f32x4 bv = xp[j * 32];
 #pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xrow[c2 * 2 * XS + j * 32], acc[0][j], 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4)
+              acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bv[s4], acc[0][j], 0, 0, 0);
+          }
         }
       }
     }
-    }   // ci0 >= 0
+
     if (more) {
       __syncthreads();            // every wave is done reading the previous chunk from LDS
       // ---- commit: registers -> LDS, activation / conditioning applied on the way
 #pragma unroll
       for (int u = 0; u < NW; ++u) {
         const int e = tid + 256 * u;
-        if (e < totalW) reinterpret_cast<f32x4*>(Ws)[e] = wreg[u];   // Ws[row][q] is linear in e
+        if (e < totalW) Ws[e] = wreg[u];                     // LDS order == copy order
       }
-      int row = tid / XL, col = tid - row * XL;
+      int P = tid / XL, col = tid - P * XL;
 #pragma unroll
-      for (int u = 0; u < NX; ++u) {
-        if (row < CK) {
-          float v = 0.f;
+      for (int u = 0; u < NXP; ++u) {
+        if (P < 2 * G) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (xoff[u] >= 0) {
-            const float cadd = a.chan_add ? a.chan_add[b * a.Cin + cn + row] : 0.f;
-            v = lrelu(xreg[u] + cadd, a.in_slope);
+            v = xreg[u];
+            if (a.chan_add) {
+              const float* ca = a.chan_add + b * a.Cin + cn + (P >> 1) * 8 + (P & 1);
+              v[0] += ca[0]; v[1] += ca[2]; v[2] += ca[4]; v[3] += ca[6];
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu(v[s4], a.in_slope);
           }
-          Xs[row * XS + col] = v;
+          Xs[P * XL + col] = v;
         }
         col += 256;
-        if (col >= XL) { col -= XL; ++row; }
-        if (col >= XL) { col -= XL; ++row; }
+        if (col >= XL) { col -= XL; ++P; }
+        if (col >= XL) { col -= XL; ++P; }
       }
       __syncthreads();
     }
@@ -328,14 +332,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
 
 template <int WM, int WN, int CK>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = 64 * WM, BN = 64 * WN, G = CK / 8;
   const int XL = BN + (a.K - 1) * a.dil;
-  // + 2 rows of padding: the operand prefetch runs one K-step past the weight slab
-  const size_t lds_floats = ((size_t)(CK * XL + 3) & ~(size_t)3) + (size_t)a.K * CK * BM + 2 * BM;
+  // float4 units: input image + weight slab + one step of padding for the operand prefetch overrun
+  const size_t lds_f4 = (size_t)G * 2 * XL + (size_t)a.K * G * 2 * BM + 2 * BM;
   dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
-  static const int pipe = [] { const char* e = getenv("MBV_CONV_PIPE"); return e ? atoi(e) : 0; }();
-  if (pipe) hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, true>), grid, dim3(256), lds_floats * sizeof(float), s, a);
-  else hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, false>), grid, dim3(256), lds_floats * sizeof(float), s, a);
+  ConvArgs a2 = a;
+  static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
+  a2.debug = dbg;
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK>), grid, dim3(256), lds_f4 * 16, s, a2);
 }
 
 bool conv1d_supported(int K, int dil) {
@@ -359,7 +364,7 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
   // long sequences (flow / decoder): 64 x 128 outputs per wave halves the weight staging per FLOP
-  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 1; }();
+  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 0; }();
   const bool wide_n = widen && wide_m && a.T >= 1024;
   if (wide_m) {
     if (wide_n) launch_ck<2, 4>(a, s);

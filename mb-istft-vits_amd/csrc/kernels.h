@@ -7,8 +7,8 @@
 namespace mbv {
 
 // ---------------------------------------------------------------- conv1d (MFMA)
-// Packed weight layout for the implicit-GEMM kernels: Wp[K][Cin][Mpad], output
-// row m fastest, Mpad a multiple of 64, rows >= M zero.
+// Packed weight layout of the implicit-GEMM conv kernel (k-interleaved, see conv1d.hip):
+//   Wp[K][Cin/8][ci & 1][Mpad][(ci % 8) / 2], Mpad a multiple of 128, rows >= M zero.
 enum ConvEpilogue : int {
   EPI_STORE = 0,     // y = acc + bias  [relu] [*out_mask]
   EPI_RESID = 1,     // y = acc + bias + res (+chan_add)
@@ -26,7 +26,7 @@ struct ConvArgs {
   int x_rstride;           // elements between channel rows of x (>= Tin)
   int Cin;
   // weights
-  const float* w;          // packed [K][Cin][Mpad]
+  const float* w;          // packed, k-interleaved (above)
   const float* bias;       // [M] in packed-row order, or nullptr
   int M;                   // real output rows (packed order)
   int Mpad;
@@ -57,6 +57,7 @@ struct ConvArgs {
   int split;               // RES_SKIP
   int skip_accum;          // RES_SKIP: skip += v instead of skip = v
   int B;
+  int debug;               // timing experiments only (MBV_CONV_DEBUG): 1 = no restaging, 3 = no MFMA
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
