@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
       const f32x4* wbase = Ws + hl * BM + wm * 32 * WM + l31;       // + step * 2 * BM
       const f32x4* xbase = Xs + hl * XL + wn * 32 * WN + l31;       // + g * 2 * XL + tap * dil
       if (nact == WM) {
-        f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
+        f32x4 a0[WM], b0[WN];
+        [[maybe_unused]] f32x4 a1[WM], b1[WN];
 #define MBV_LOAD_AB(ST, AV, BV)                                                   \
         {                                                                          \
           const int st_ = (ST);                                                    \
@@ -181,20 +182,30 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
           _Pragma("unroll") for (int i = 0; i < WM; ++i)                           \
             _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
-        MBV_LOAD_AB(0, a0, b0);
-        int st = 0;
-        for (; st + 1 < nsteps; st += 2) {
-          // sched_barrier keeps hipcc from sinking the prefetch back behind the MFMAs
-          MBV_LOAD_AB(st + 1, a1, b1);
-          __builtin_amdgcn_sched_barrier(0);
-          MBV_MMA(a0, b0);
-          __builtin_amdgcn_sched_barrier(0);
-          MBV_LOAD_AB(st + 2, a0, b0);   // the last pass reads one step past the slab (padded, unused)
-          __builtin_amdgcn_sched_barrier(0);
-          MBV_MMA(a1, b1);
-          __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WN < 4) {
+          // operands double-buffered one step ahead (4 accumulators: short steps)
+          MBV_LOAD_AB(0, a0, b0);
+          int st = 0;
+          for (; st + 1 < nsteps; st += 2) {
+            // sched_barrier keeps hipcc from sinking the prefetch back behind the MFMAs
+            MBV_LOAD_AB(st + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            MBV_MMA(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            MBV_LOAD_AB(st + 2, a0, b0);   // the last pass reads one step past the slab (padded, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            MBV_MMA(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (st < nsteps) { MBV_MMA(a0, b0); }                // odd step count
+        } else {
+          // 8 accumulators: 32 MFMAs (2048 pipe cycles) per step hide the next step's LDS
+          // latency behind the co-resident wave; single operand set keeps VGPRs under 256
+          for (int st = 0; st < nsteps; ++st) {
+            MBV_LOAD_AB(st, a0, b0);
+            MBV_MMA(a0, b0);
+          }
         }
-        if (st < nsteps) { MBV_MMA(a0, b0); }                // odd step count
 #undef MBV_LOAD_AB
 #undef MBV_MMA
       } else if (nact == 1) {                                // only reachable with WM == 2
@@ -364,10 +375,11 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
   // long sequences (flow / decoder): 64 x 128 outputs per wave halves the weight staging per FLOP
-  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 0; }();
-  const bool wide_n = widen && wide_m && a.T >= 1024;
+  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
+  const int wide_n = (wide_m && a.T >= 1024) ? widen : 0;   // 3 / 4: 6 / 8 accumulator tiles per wave
   if (wide_m) {
-    if (wide_n) launch_ck<2, 4>(a, s);
+    if (wide_n == 4) launch_ck<2, 4>(a, s);
+    else if (wide_n == 3) launch_ck<2, 3>(a, s);
     else launch_ck<2, 2>(a, s);
   } else {
     launch_ck<1, 2>(a, s);
