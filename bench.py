@@ -129,6 +129,11 @@ def main():
     Tp = o.shape[-1] // cfg.samples_per_frame
     value = valid_samples * args.steps / elapsed
 
+    stage_ms = None
+    if rank == 0:
+        out = net.infer(x[:B], xl[:B], sid[:B] if sid is not None else None, noise_scale=0, length_scale=1)
+        stage_ms = {k: round(v * 1e3, 3) for k, v in dict(out[7]).items()}
+
     # ---- roofline of the fused iSTFT+PQMF launch, waveform-only mode ----
     roof, roof_conv = None, None
     if rank == 0:
@@ -189,7 +194,7 @@ def main():
                        "valid_samples_per_step": valid_samples, "sampling_rate": sr,
                        "parallelism": "utterance-sharded dp%d" % world},
             "rtf": round((elapsed / args.steps) / (valid_samples / sr), 7),
-            "roofline": roof, "roofline_conv": roof_conv, "cpu_baseline": cpu,
+            "stage_ms": stage_ms, "roofline": roof, "roofline_conv": roof_conv, "cpu_baseline": cpu,
         }
         if cpu:
             line["gpu_over_cpu_rtf"] = round(cpu["rtf"] / line["rtf"], 1)

@@ -161,13 +161,13 @@ def duration_predictor(W, cfg, x, x_mask, g=None):
     return F.conv1d(h * x_mask, W.w("dp.proj"), W.b("dp.proj")) * x_mask
 
 
-def length_regulate(logw, x_mask, m_p, logs_p, length_scale=1.0):
+def length_regulate(logw, x_mask, m_p, logs_p, length_scale=1.0, t_frames=None):
     """models.py:717-725 + commons.generate_path (commons.py:128-143).
     The attn-matmul is restated as what it is: token t repeated w_ceil[t] times."""
     w = torch.exp(logw) * x_mask * length_scale
     w_ceil = torch.ceil(w)                                    # [B,1,T]
     y_lengths = torch.clamp_min(w_ceil.sum(dim=(1, 2)), 1).long()
-    Tp = int(y_lengths.max())
+    Tp = int(y_lengths.max()) if t_frames is None else int(t_frames)   # t_frames: pad to a larger batch's T'
     y_mask = sequence_mask(y_lengths, Tp)
     cum = torch.cumsum(w_ceil[:, 0, :], dim=-1)               # [B,T]
     frames = torch.arange(Tp, dtype=cum.dtype)[None, :, None]  # [1,T',1]
@@ -376,7 +376,7 @@ def decode(sd, cfg, z, g=None, taps=None):
 # the whole path (models.py:697-737)
 # --------------------------------------------------------------------------
 def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_scale=1.0,
-          max_len=None, want_taps=False):
+          max_len=None, want_taps=False, t_frames=None):
     """Returns a dict with every stage boundary of `SynthesizerTrn.infer`.
     `noise` replaces torch.randn_like(m_p) (models.py:729); None == zeros."""
     W = sd if isinstance(sd, Weights) else Weights(sd)
@@ -390,7 +390,7 @@ def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_s
             g = W["emb_g.weight"][torch.as_tensor(sid).long()].unsqueeze(-1)
         logw = duration_predictor(W, cfg, x, x_mask, g)
         w_ceil, y_lengths, y_mask, attn, m_p, logs_p = length_regulate(
-            logw, x_mask, m_t, logs_t, length_scale)
+            logw, x_mask, m_t, logs_t, length_scale, t_frames)
         if noise is None or noise_scale == 0:
             z_p = m_p + torch.zeros_like(m_p) * torch.exp(logs_p) * noise_scale
         else:

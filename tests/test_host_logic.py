@@ -1,0 +1,143 @@
+"""CPU-only checks of the host side: drop-in API surface, hps handling, C-ABI library
+symbols, error behaviour without a GPU.  No compute is launched here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mb_istft_vits_amd import _capi, models, spec, synth, utils
+from helpers import config_for, FIXTURES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _net(name="ljs_mini_mb_istft_vits"):
+    hps = utils.get_hparams_from_file(utils.builtin_config(name))
+    return hps, models.SynthesizerTrn(59, hps.data.filter_length // 2 + 1,
+                                      hps.train.segment_size // hps.data.hop_length,
+                                      n_speakers=hps.data.n_speakers, **hps.model)
+
+
+def test_header_symbols_all_exported():
+    """Every function `include/mbistft_vits.h` declares is exported by the built library."""
+    hdr = open(os.path.join(ROOT, "include", "mbistft_vits.h")).read()
+    declared = set(re.findall(r"\b(mbv_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mbv_model", "mbv_config", "mbv_outputs"}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    L = _capi.lib()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert L.mbv_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header():
+    # 8 + 1 + 3 + 9 + 4 int32 fields
+    assert C.sizeof(_capi.MbvConfig) == 4 * (9 + 3 + 9 + 4)
+    assert C.sizeof(_capi.MbvOutputs) == 8 * 10
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config():
+    L = _capi.lib()
+    h = C.c_void_p()
+    c = _capi.MbvConfig()
+    c.struct_bytes = 7                         # ABI mismatch
+    assert L.mbv_create(C.byref(c), C.byref(h)) != 0
+    assert b"struct_bytes" in L.mbv_last_error(None)
+    if not torch.cuda.is_available():
+        c.struct_bytes = C.sizeof(_capi.MbvConfig)
+        c.n_vocab, c.inter_channels, c.hidden_channels, c.filter_channels = 59, 192, 192, 768
+        c.n_heads, c.n_layers, c.kernel_size, c.upsample_initial_channel = 2, 6, 3, 512
+        for j, k in enumerate((3, 7, 11)):
+            c.resblock_kernel_sizes[j] = k
+            for q, d in enumerate((1, 3, 5)):
+                c.resblock_dilations[j][q] = d
+        assert L.mbv_create(C.byref(c), C.byref(h)) != 0
+        assert b"no CPU fallback" in L.mbv_last_error(None)
+
+
+def test_state_dict_keys_match_reference_contract():
+    for name in set(FIXTURES.values()):
+        _, net = _net(name)
+        keys = list(net.state_dict().keys())
+        want = spec.param_shapes(net.cfg)
+        assert keys == list(want.keys())
+        for k, t in net.state_dict().items():
+            assert tuple(t.shape) == tuple(want[k]), k
+    # counts probed from the reference in SURVEY §8a (uudb: 383 non-enc_q keys)
+    _, net = _net("uudb_ms_istft_vits_ms")
+    assert len(net.state_dict()) == 383
+    assert hasattr(net, "emb_g") and net.n_speakers == 12 and callable(net.dec)
+
+
+def test_load_checkpoint_is_key_tolerant(tmp_path):
+    hps, net = _net()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    dropped = "dec.conv_pre.bias"
+    saved = {k: v + 1.0 for k, v in sd.items() if k != dropped}
+    saved["enc_q.pre.weight"] = torch.zeros(3)             # training-only key in real checkpoints
+    path = tmp_path / "G_1.pth"
+    torch.save({"model": saved, "iteration": 7, "optimizer": None, "learning_rate": 2e-4}, path)
+    m, opt, lr, it = utils.load_checkpoint(str(path), net, None)
+    assert (it, lr, opt) == (7, 2e-4, None) and m is net
+    new = net.state_dict()
+    assert torch.equal(new[dropped], sd[dropped])          # kept (utils.py:35-40)
+    assert torch.equal(new["enc_p.emb.weight"], sd["enc_p.emb.weight"] + 1.0)
+
+
+def test_hparams_behaves_like_reference():
+    hps = utils.get_hparams_from_file(utils.builtin_config("ljs_mb_istft_vits"))
+    assert hps.model.n_heads == 2 and hps["model"]["n_heads"] == 2
+    assert "model" in hps and len(hps.model) == len(list(hps.model.keys()))
+    kw = dict(**hps.model)
+    assert kw["mb_istft_vits"] is True and kw["subbands"] == 4
+    hps.train["seed"] = 5
+    assert hps.train.seed == 5
+
+
+def test_ctor_rejects_what_is_out_of_scope():
+    hps = utils.get_hparams_from_file(utils.builtin_config("ljs_mb_istft_vits"))
+    kw = dict(**hps.model)
+    with pytest.raises(ValueError):
+        models.SynthesizerTrn(59, 513, 32, **{**kw, "use_sdp": True})
+    with pytest.raises(ValueError):
+        models.SynthesizerTrn(59, 513, 32, **{**kw, "mb_istft_vits": False, "istft_vits": True})
+    with pytest.raises(ValueError):
+        models.SynthesizerTrn(59, 513, 32, **{**kw, "mb_istft_vits": False})   # "Decoder Error"
+    with pytest.raises(ValueError):
+        models.SynthesizerTrn(59, 513, 32, **{**kw, "resblock": "2"})
+
+
+def test_cpu_model_raises_instead_of_falling_back():
+    _, net = _net()
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        net.infer(torch.zeros(1, 4, dtype=torch.long), torch.tensor([4]))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        net.dec(torch.zeros(1, 192, 4))
+    with pytest.raises(NotImplementedError):
+        net.voice_conversion(None, None, None, None)
+
+
+def test_synthetic_checkpoint_is_deterministic_and_usable():
+    _, cfg = config_for("ljs_mb_istft_vits")
+    a, b = synth.make_state_dict(cfg, 1234), synth.make_state_dict(cfg, 1234)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = synth.make_state_dict(cfg, 1235)
+    assert not np.array_equal(a["dec.conv_pre.weight_v"], c["dec.conv_pre.weight_v"])
+    assert np.abs(a["flow.flows.0.post.weight"]).max() > 0          # flows are not the identity
+    assert np.allclose(a["dp.proj.bias"], np.log(2.5))
+    x, xl, sid = synth.synthetic_batch(cfg, 8, 200, seed=0, ragged=True)
+    assert x.shape == (8, 200) and xl.max() == 200 and sid is None
+    assert all((x[i, xl[i]:] == 0).all() and (x[i, :xl[i]] > 0).all() for i in range(8))
+
+
+def test_bench_flop_model_matches_survey():
+    import bench
+    _, cfg = config_for("ljs_mb_istft_vits")
+    assert abs(bench.decoder_flops_per_frame(cfg) / 1e6 - 143.9) < 0.1
+    _, mini = config_for("ljs_mini_mb_istft_vits")
+    assert abs(bench.decoder_flops_per_frame(mini) / 1e6 - 36.8) < 0.1
+    assert bench.ISTFT_BYTES_PER_FRAME == 5632
