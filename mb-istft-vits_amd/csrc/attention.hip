@@ -90,13 +90,14 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.f;
     const int tkl = tk0 + l31;
+    // all K fragments of the tile first (one latency round), then the MFMA chain
+    float kf[DMAX / 2];
 #pragma unroll
-    for (int s = 0; s < DMAX / 2; ++s) {
-      if (s < nsteps) {
-        const float av = tkl < T ? kb[(int64_t)(2 * s + hl) * T + tkl] : 0.f;
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], S, 0, 0, 0);
-      }
-    }
+    for (int s = 0; s < DMAX / 2; ++s)
+      kf[s] = (s < nsteps && tkl < T) ? kb[(int64_t)(2 * s + hl) * T + tkl] : 0.f;
+#pragma unroll
+    for (int s = 0; s < DMAX / 2; ++s)
+      if (s < nsteps) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], S, 0, 0, 0);
     const bool near = (tk0 - tq0) <= 35 && (tq0 - tk0) <= 35;   // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

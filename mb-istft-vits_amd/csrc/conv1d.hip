@@ -374,12 +374,18 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
-  // long sequences (flow / decoder): 64 x 128 outputs per wave halves the weight staging per FLOP
+  // Wave tile along time: 2 x 32 columns (block 128) or 3 x 32 (block 192, 6 accumulators per
+  // wave: ~6 % better matrix-pipe use) - whichever wastes fewer padded columns.
   static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
-  const int wide_n = (wide_m && a.T >= 1024) ? widen : 0;   // 3 / 4: 6 / 8 accumulator tiles per wave
+  int wn = 2;
+  if (wide_m && widen >= 3 && a.T >= 192) {
+    const double eff2 = 0.94 * a.T / (double)(((a.T + 127) / 128) * 128);
+    const double eff3 = a.T / (double)(((a.T + 191) / 192) * 192);
+    if (eff3 >= eff2) wn = widen;
+  }
   if (wide_m) {
-    if (wide_n == 4) launch_ck<2, 4>(a, s);
-    else if (wide_n == 3) launch_ck<2, 3>(a, s);
+    if (wn == 4) launch_ck<2, 4>(a, s);
+    else if (wn == 3) launch_ck<2, 3>(a, s);
     else launch_ck<2, 2>(a, s);
   } else {
     launch_ck<1, 2>(a, s);
