@@ -381,7 +381,9 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   if (wide_m && widen >= 3 && a.T >= 192) {
     const double eff2 = 0.94 * a.T / (double)(((a.T + 127) / 128) * 128);
     const double eff3 = a.T / (double)(((a.T + 191) / 192) * 192);
-    if (eff3 >= eff2) wn = widen;
+    // small launches: the longer 192-column blocks quantise badly over 2 blocks x 256 CUs
+    const long blocks3 = (long)((a.T + 191) / 192) * ((a.M + 127) / 128) * a.B;
+    if (eff3 >= eff2 && blocks3 >= 1024) wn = widen;
   }
   if (wide_m) {
     if (wn == 4) launch_ck<2, 4>(a, s);
