@@ -163,24 +163,18 @@ __device__ __forceinline__ void irfft16_hann(const float* re, const float* im, f
 
 // `taps` (device, 256 floats, only read by the trainable-bank variant):
 //   t[band][p][i] = 4 h[band][3 - p + 4 i]   (x4 up-sampling gain folded in; 0 where the tap is > 62)
-// TMAX: largest tile (sub-band samples per band); the launcher picks the actual tile length
-// `tm` <= TMAX (multiple of 4) so that the grid is a whole number of resident-workgroup rounds
-// of equal-work tiles (no tail round, no half-empty last tile per utterance).
-template <int TMAX, int NTHREADS, bool FIXED, bool FAST>
+template <int TM, int NTHREADS, bool FIXED, bool FAST>
 __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, const float* __restrict__ taps,
-                                                              int tiles_per_utt, int total_tiles, int tm) {
-  constexpr int NFMAX = TMAX / 4 + 7;     // frames a tile touches per band (max)
-  constexpr int NFS = ((NFMAX + 31) / 32) * 32 + 8;   // LDS frame stride, == 8 (mod 32): conflict-free phase B
-  constexpr int YLS = TMAX + 16;          // row stride of the phase-B product
+                                                              int tiles_per_utt, int total_tiles) {
+  constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
+  constexpr int NFS = ((NF + 31) / 32) * 32 + 8;   // LDS frame stride, == 8 (mod 32): conflict-free phase B
+  constexpr int YL = TM + 16;             // sub-band samples incl. PQMF halo
   constexpr int NROW = FIXED ? 8 : 4;     // rows of the phase-B product (U_q or y_band)
-  static_assert(4 * NFMAX <= NTHREADS, "one lane per (band, frame)");
-  static_assert(YLS <= NTHREADS, "one lane per sub-band time index");
-  static_assert(NROW * YLS <= 4 * 16 * NFS, "phase-B product aliases the frame buffer");
+  static_assert(4 * NF <= NTHREADS, "one lane per (band, frame)");
+  static_assert(YL <= NTHREADS, "one lane per sub-band time index");
+  static_assert(NROW * YL <= 4 * 16 * NFS, "phase-B product aliases the frame buffer");
   __shared__ __attribute__((aligned(16))) float fr[4 * 16 * NFS];
   float* const prod = fr;                 // reused after the frames are consumed
-  const int TM = tm;
-  const int NF = TM / 4 + 7;              // frames this tile touches per band
-  const int YL = TM + 16;                 // sub-band samples incl. PQMF halo
 
   // XCD-aware tile order: workgroups with equal (id % 8) share an L2; give each
   // of the 8 groups a contiguous run of tiles so halo rows are re-read on-die.
@@ -285,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   __syncthreads();                        // every lane has consumed its frames: reuse the buffer
   if (tid < YL) {
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) prod[k * YLS + tid] = rowv[k];
+    for (int k = 0; k < NROW; ++k) prod[k * YL + tid] = rowv[k];
   }
   __syncthreads();
 
@@ -300,13 +294,13 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int j = 3 - p + 4 * i;           // tap index; y index m - 7 + i
-            if (j <= 62) acc[p] = fmaf(PQMF_G[j], prod[(j & 7) * YLS + tid + 1 + i], acc[p]);
+            if (j <= 62) acc[p] = fmaf(PQMF_G[j], prod[(j & 7) * YL + tid + 1 + i], acc[p]);
           }
         }
       } else {
 #pragma unroll
         for (int band = 0; band < 4; ++band) {
-          const float* yb = &prod[band * YLS + tid + 1];       // y[m - 7 + i]
+          const float* yb = &prod[band * YL + tid + 1];        // y[m - 7 + i]
           const float* hb = taps + band * 64;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -323,32 +317,17 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
 }
 
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
-  constexpr int TMAX = 480, NT = 512;
+  constexpr int TM = 480, NT = 512;
   const int M = 64 * a.Tp;
-  // Tile length: start from the largest tile, then shrink it so that B * tiles fills whole
-  // rounds of the resident workgroups (4 per CU x 256 CUs) with equal-work tiles.
-  int tiles_per_utt = (M + TMAX - 1) / TMAX;
-  {
-    const long slots = 4L * 256;
-    const long total0 = (long)tiles_per_utt * a.B;
-    if (total0 > slots) {
-      const long rounds = (total0 + slots - 1) / slots;
-      const long n = rounds * slots / a.B;            // tiles per utterance that still fit `rounds`
-      if (n > tiles_per_utt) tiles_per_utt = (int)n;
-    }
-  }
-  int tm = ((M + tiles_per_utt - 1) / tiles_per_utt + 3) & ~3;
-  if (tm > TMAX) tm = TMAX;
-  if (tm < 4) tm = 4;
-  tiles_per_utt = (M + tm - 1) / tm;
+  const int tiles_per_utt = (M + TM - 1) / TM;
   const int total = tiles_per_utt * a.B;
   const dim3 grid(total), block(NT);
   if (a.fixed_bank) {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TMAX, NT, true, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total, tm);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TMAX, NT, true, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total, tm);
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
   } else {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TMAX, NT, false, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total, tm);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TMAX, NT, false, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total, tm);
+    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
+    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
   }
 }
 
