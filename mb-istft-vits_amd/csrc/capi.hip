@@ -617,6 +617,8 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   }
   const int Fr = L + 1;
   const int chl = C0 >> 2;
+  if ((int64_t)B * 72 * Fr * 4 >= (1LL << 31))
+    return m->fail("batch x frames too large for one launch (x_post must stay below 2 GiB): split the batch");
   float* xpost = sc.take<float>((size_t)B * 72 * Fr);
   {
     ConvArgs a = conv_args(m, m->conv_post, cur, (int64_t)chl * L, L, xpost, (int64_t)72 * Fr, Fr, B);
@@ -988,6 +990,8 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
                    int multistream, float* o, float* o_mb, float* spec, float* phase, void* stream) {
   if (!m) return 1;
   if (!x_post || !o || B <= 0 || t_frames <= 0) return m->fail("mbv_istft_pqmf: bad arguments");
+  if ((int64_t)B * 72 * (16 * (int64_t)t_frames + 1) * 4 >= (1LL << 31))
+    return m->fail("mbv_istft_pqmf: B * T' too large for one launch (x_post must stay below 2 GiB)");
   HIPCHK(m, hipSetDevice(m->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   float*& d_tab = m->user_tab;

@@ -190,6 +190,14 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   const int M = 64 * Tp;                  // sub-band samples per band
   const int tid = threadIdx.x;
   const int f_lo = m0 / 4 - 3;
+  // raw buffer descriptors (stride 0, byte range of the whole tensor; launcher checks < 4 GiB)
+  constexpr int kRsrcFlags = 0x00020000;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x_post), 0, a.B * 72 * F * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t srsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.spec, 0, a.spec ? a.B * 36 * F * 4 : 0, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t prsrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.phase, 0, a.phase ? a.B * 36 * F * 4 : 0, kRsrcFlags);
 
   // ---------------- phase A: frames --------------------------------------
   if (tid < 4 * NF) {
@@ -197,12 +205,12 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
     const int f = f_lo + fl;
     float out[16];
     if (f >= 0 && f < F) {
-      // uniform 64-bit base + 32-bit lane offset (launch_istft_pqmf checks the tensor is < 4 GiB)
-      const float* xb = a.x_post + (int64_t)b * 72 * F;
-      const unsigned int off = (unsigned int)(band * 18 * F + f);
+      // buffer loads: one 32-bit lane offset, the 18 channel strides ride in scalar registers
+      const int voff = ((b * 72 + band * 18) * F + f) * 4;
       float xin[18];
 #pragma unroll
-      for (int k = 0; k < 18; ++k) xin[k] = xb[off + (unsigned int)(k * F)];
+      for (int k = 0; k < 18; ++k)
+        xin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, k * F * 4, 0));
       float re[9], im[9];
       // frame f is owned (for the spec/phase outputs) by the tile holding sample 4f
       const bool own = (4 * f >= m0 && 4 * f < m0 + TM) || (f == F - 1 && m0 + TM >= M);
@@ -211,8 +219,9 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
         float mag, ph;
         polar<FAST>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
         if (own) {
-          if (a.spec) a.spec[(((int64_t)b * 4 + band) * 9 + k) * F + f] = mag;
-          if (a.phase) a.phase[(((int64_t)b * 4 + band) * 9 + k) * F + f] = ph;
+          const int so = ((b * 4 + band) * 9 * F + f) * 4;
+          if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
+          if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 0);
         }
       }
       irfft16_hann(re, im, out);
