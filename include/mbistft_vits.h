@@ -151,7 +151,9 @@ int mbv_kernel_times_ms(mbv_model *m, float out[2]);
  * (models.py:463-465), including exp / pi*sin of models.py:368-369.
  *   x_post  fp32 [B, 72, F]  F = 16 T' + 1 (output of subband_conv_post)
  *   filter  fp32 [4, 63] device synthesis filter, NULL = the PQMF design
- *   multistream  non-zero: o_mb is the zero-stuffed [B,4,256T'] tensor
+ *   multistream  bit 0: o_mb is the zero-stuffed [B,4,256T'] tensor (MS decoder);
+ *                bit 1: x_post is in the library's internal units (log-magnitude rows times
+ *                log2 e, phase rows divided by 2 pi), as the decoder stack produces it
  * Does not need a model handle's weights; `m` provides device + scratch. */
 int mbv_istft_pqmf(mbv_model *m, const float *x_post, int B, int t_frames, const float *filter,
                    int multistream, float *o, float *o_mb, float *spec, float *phase,

@@ -77,6 +77,7 @@ struct mbv_model {
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
   bool user_tab_is_pqmf = false;
+  int xpost_F = 1;             // frames per row of the last x_post stage tensor
   int exact_math = 0;          // MBV_ISTFT_EXACT=1: libm transcendentals in the iSTFT kernel
 
   // state of the last encode
@@ -488,7 +489,21 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       m->rb[n].cb = P.vec(std::string(p) + "bias");
     }
   }
-  m->conv_post = P.conv_plain("dec.subband_conv_post");
+  {   // subband_conv_post, rows pre-scaled for the fused iSTFT kernel: exp(x) = 2^(x log2 e),
+      // sin(x) = sin_turns(x / 2 pi)  (istft_pqmf.hip, template PRE)
+    std::vector<float> w = P.dense("dec.subband_conv_post");
+    std::vector<float> bsc = P.t("dec.subband_conv_post.bias").data;
+    const auto& sh = P.t("dec.subband_conv_post.weight_v").shape;
+    const int Cout = (int)sh[0], Cin = (int)sh[1], K = (int)sh[2];
+    for (int co = 0; co < Cout; ++co) {
+      const float sc = (co % 18) < 9 ? 1.44269504088896341f : 0.15915494309189535f;
+      for (int j = 0; j < Cin * K; ++j) w[(size_t)co * Cin * K + j] *= sc;
+      bsc[co] *= sc;
+    }
+    std::vector<int> rows(Cout);
+    for (int i = 0; i < Cout; ++i) rows[i] = i;
+    m->conv_post = P.conv(w, Cout, Cin, K, rows, {}, &bsc, nullptr);
+  }
   if (c.decoder == MBV_DEC_MULTISTREAM) {
     const std::vector<float> h = P.dense("dec.multistream_conv_post");   // [1][4][63]
     m->filt = P.vec_data(synthesis_table(h.data()));
@@ -627,6 +642,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
     launch_conv1d(a, s);
   }
   m->stages["x_post"] = {xpost, (int64_t)B * 72 * Fr};
+  m->xpost_F = Fr;
   float* o = outs ? outs->o : nullptr;
   float* otmp = nullptr;
   if (!o) { otmp = sc.take<float>((size_t)B * 256 * Td); o = otmp; }
@@ -635,7 +651,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
   ia.phase = outs ? outs->phase : nullptr;
   ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
-  ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math;
+  ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
   HIPCHK(m, hipEventRecord(m->evk[1], s));
   launch_istft_pqmf(ia, s);
   HIPCHK(m, hipEventRecord(m->evk[2], s));
@@ -1011,8 +1027,8 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   }
   IstftArgs a{};
   a.x_post = x_post; a.filt = d_tab; a.o = o; a.o_mb = o_mb; a.spec = spec; a.phase = phase;
-  a.B = B; a.Tp = t_frames; a.multistream = multistream;
-  a.fixed_bank = filter == nullptr; a.exact_math = m->exact_math;
+  a.B = B; a.Tp = t_frames; a.multistream = multistream & 1;
+  a.fixed_bank = filter == nullptr; a.exact_math = m->exact_math; a.prescaled = (multistream >> 1) & 1;
   launch_istft_pqmf(a, s);
   HIPCHK(m, hipGetLastError());
   return 0;
@@ -1044,6 +1060,10 @@ int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capac
   src = it->second.ptr; numel = it->second.numel;
   if (!dst) return numel;
   if (capacity < numel) { m->fail("capacity too small"); return -1; }
+  if (n == "x_post") {     // stored pre-scaled for the iSTFT kernel: hand back the reference's units
+    launch_unscale_xpost(src, dst, (int)(numel / (72 * (int64_t)m->xpost_F)), m->xpost_F, (hipStream_t)stream);
+    return numel;
+  }
   if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
     m->fail("hipMemcpyAsync failed"); return -1;
   }

@@ -89,19 +89,22 @@ __device__ constexpr float PQMF_G[64] = {
     -4.045689129e-04f, -2.144142782e-04f, -6.692762690e-05f, 0.000000000e+00f,
 };
 
-template <bool FAST>
+// PRE: the producing conv already scaled the log-magnitude rows by log2(e) and the phase rows by
+// 1/(2 pi) (folded into subband_conv_post's packed weights), so exp2 / sin-in-turns apply directly.
+template <bool FAST, bool PRE>
 __device__ __forceinline__ void polar(float xm, float xp, float& mag, float& ph, float& re,
                                       float& im, bool need_im) {
   if constexpr (FAST) {
-    // hardware transcendentals: v_exp_f32 (2^x), v_sin_f32 / v_cos_f32 (argument in turns).
-    // pi*sin(x) in turns is 0.5*sin(x): no multiply by pi on the path to cos/sin.
-    mag = __builtin_amdgcn_exp2f(xm * 1.44269504088896341f);
-    const float t = xp * 0.15915494309189535f;
-    const float s = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+    // hardware transcendentals: v_exp_f32 (2^x), v_sin_f32 / v_cos_f32 (argument in turns, valid
+    // for |turns| <= 256, i.e. |x| <= 1608 rad).  pi*sin(x) in turns is 0.5*sin(x): no multiply
+    // by pi on the path to cos/sin.
+    mag = __builtin_amdgcn_exp2f(PRE ? xm : xm * 1.44269504088896341f);
+    const float s = __builtin_amdgcn_sinf(PRE ? xp : xp * 0.15915494309189535f);
     ph = kPi * s;
     re = mag * __builtin_amdgcn_cosf(0.5f * s);
     im = need_im ? mag * __builtin_amdgcn_sinf(0.5f * s) : 0.f;
   } else {
+    if constexpr (PRE) { xm *= 0.69314718055994531f; xp *= 6.28318530717958648f; }
     mag = expf(xm);
     ph = kPi * sinf(xp);
     float sn, cs;
@@ -163,7 +166,7 @@ __device__ __forceinline__ void irfft16_hann(const float* re, const float* im, f
 
 // `taps` (device, 256 floats, only read by the trainable-bank variant):
 //   t[band][p][i] = 4 h[band][3 - p + 4 i]   (x4 up-sampling gain folded in; 0 where the tap is > 62)
-template <int TM, int NTHREADS, bool FIXED, bool FAST>
+template <int TM, int NTHREADS, bool FIXED, bool FAST, bool PRE>
 __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, const float* __restrict__ taps,
                                                               int tiles_per_utt, int total_tiles) {
   constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         float mag, ph;
-        polar<FAST>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
+        polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
         if (own) {
           const int so = ((b * 4 + band) * 9 * F + f) * 4;
           if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
@@ -331,13 +334,20 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
   const int tiles_per_utt = (M + TM - 1) / TM;
   const int total = tiles_per_utt * a.B;
   const dim3 grid(total), block(NT);
-  if (a.fixed_bank) {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, true, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
-  } else {
-    if (a.exact_math) hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, false>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
-    else hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, false, true>), grid, block, 0, s, a, a.filt, tiles_per_utt, total);
+#define MBV_ISTFT_LAUNCH(FIXED, FAST, PRE) \
+  hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, FIXED, FAST, PRE>), grid, block, 0, s, a, a.filt, tiles_per_utt, total)
+  const int variant = (a.fixed_bank ? 4 : 0) | (a.exact_math ? 0 : 2) | (a.prescaled ? 1 : 0);
+  switch (variant) {
+    case 0: MBV_ISTFT_LAUNCH(false, false, false); break;
+    case 1: MBV_ISTFT_LAUNCH(false, false, true); break;
+    case 2: MBV_ISTFT_LAUNCH(false, true, false); break;
+    case 3: MBV_ISTFT_LAUNCH(false, true, true); break;
+    case 4: MBV_ISTFT_LAUNCH(true, false, false); break;
+    case 5: MBV_ISTFT_LAUNCH(true, false, true); break;
+    case 6: MBV_ISTFT_LAUNCH(true, true, false); break;
+    default: MBV_ISTFT_LAUNCH(true, true, true); break;
   }
+#undef MBV_ISTFT_LAUNCH
 }
 
 }  // namespace mbv

@@ -115,8 +115,12 @@ struct IstftArgs {
   int B, Tp, multistream;
   int fixed_bank;        // 1: the PQMF design (cosine-modulated, factorised); 0: arbitrary 4x63 taps
   int exact_math;        // 1: libm expf/sinf/sincosf instead of the hardware transcendentals
+  int prescaled;         // 1: x_post rows already carry log2(e) (magnitude) / 1/(2 pi) (phase)
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
+
+// x_post rows back to the reference's units (stage introspection): inverse of the pre-scaling
+void launch_unscale_xpost(const float* src, float* dst, int B, int F, hipStream_t s);
 
 // misc
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);

@@ -6,9 +6,10 @@ import torch
 from mb_istft_vits_amd import _capi
 
 
-def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None):
+def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True):
     """Average duration (ms) of the fused iSTFT+PQMF launch in waveform-only mode on a
-    [B, 72, 16 Tp + 1] input, HIP events on the launch stream."""
+    [B, 72, 16 Tp + 1] input, HIP events on the launch stream.  prescaled=True times the variant
+    the decoder stack uses (x_post in the library's internal units, see mbistft_vits.h)."""
     dev = net._device()
     h = net._ensure_handle()
     L = _capi.lib()
@@ -21,7 +22,7 @@ def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None):
     sp = C.c_void_p(stream.cuda_stream)
 
     def launch():
-        rc = L.mbv_istft_pqmf(h, C.c_void_p(x_post.data_ptr()), B, Tp, None, 0,
+        rc = L.mbv_istft_pqmf(h, C.c_void_p(x_post.data_ptr()), B, Tp, None, 2 if prescaled else 0,
                               C.c_void_p(o.data_ptr()), None, None, None, sp)
         _capi.check(h, rc, "mbv_istft_pqmf")
     for _ in range(5):
