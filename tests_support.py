@@ -25,12 +25,18 @@ def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True):
         rc = L.mbv_istft_pqmf(h, C.c_void_p(x_post.data_ptr()), B, Tp, None, 2 if prescaled else 0,
                               C.c_void_p(o.data_ptr()), None, None, None, sp)
         _capi.check(h, rc, "mbv_istft_pqmf")
-    for _ in range(5):
+    for _ in range(10):
         launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        launch()
-    e1.record(stream)
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    # several event-bracketed batches; the median batch is reported (single batches on this pool
+    # scatter by +-5 % with clock / cache state)
+    times = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            launch()
+        e1.record(stream)
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) / iters)
+    times.sort()
+    return times[len(times) // 2]
