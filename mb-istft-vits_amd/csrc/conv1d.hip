@@ -43,17 +43,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int WM, int WN, int CK>
-__global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
-  constexpr int BM = 64 * WM;      // 2 waves x WM tiles of 32 rows
-  constexpr int BN = 64 * WN;      // 2 waves x WN tiles of 32 columns
-  constexpr int G = CK / 8;        // channel groups (4 K-steps each) per chunk
+// NWN = waves along time.  NWN == 2: 256 threads, single LDS buffer, 2 barriers per chunk,
+// several workgroups per CU (short sequences / small launches).  NWN == 4: 512 threads = one
+// workgroup per CU with 2 waves per SIMD, the weight slab shared by twice as many columns,
+// DOUBLE-buffered LDS: chunk c+1 is committed into the other buffer right after the MFMA loop of
+// chunk c, one barrier per chunk, waves drift apart instead of staging in lockstep.
+template <int WM, int WN, int CK, int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kernel(const ConvArgs a) {
+  constexpr int NT = 128 * NWN;          // threads
+  constexpr bool DB = NWN == 4;          // double-buffered LDS
+  constexpr int BM = 64 * WM;            // 2 waves x WM tiles of 32 rows
+  constexpr int BN = 32 * WN * NWN;      // NWN waves x WN tiles of 32 columns
+  constexpr int G = CK / 8;              // channel groups (4 K-steps each) per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int hl = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * BM;
@@ -61,8 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
 
   const int halo = (a.K - 1) * a.dil;
   const int XL = BN + halo;                            // staged columns
-  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);     // [G][2][XL]   (x4 K-steps)
-  f32x4* const Ws = Xs + G * 2 * XL;                   // [K][G][2][BM] (x4 K-steps)
+  // one LDS buffer: input image [G][2][XL] + weight slab [K][G][2][BM] (+ 2*BM prefetch overrun)
+  const int buf_f4 = G * 2 * XL + a.K * G * 2 * BM + 2 * BM;
+  f32x4* const lds4 = reinterpret_cast<f32x4*>(lds);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -84,9 +92,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   // ---- async-stage bookkeeping ------------------------------------------------
   constexpr int HALO_MAX = CK == 8 ? 72 : (CK == 16 ? 24 : 0);
   constexpr int KMAX = CK == 8 ? 11 : (CK == 16 ? 5 : 1);
-  constexpr int NXP = (G * 2 * (BN + HALO_MAX) + 255) / 256;   // (group, h, col) items per thread
-  constexpr int NW = (KMAX * G * 2 * BM + 255) / 256;          // weight float4 per thread
-  constexpr int RPI = 256 / BM;                                // weight rows [BM x f32x4] per pass
+  constexpr int NXP = (G * 2 * (BN + HALO_MAX) + NT - 1) / NT;   // (group, h, col) items per thread
+  constexpr int NW = (KMAX * G * 2 * BM + NT - 1) / NT;        // weight float4 per thread
+  constexpr int RPI = NT / BM;                                 // weight rows [BM x f32x4] per pass
   constexpr int ROWS_PER_TAP = 2 * G;
   static_assert(RPI % ROWS_PER_TAP == 0 || ROWS_PER_TAP % RPI == 0, "weight-row decomposition");
   f32x4 wreg[NW];
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   const int64_t tap_stride = (int64_t)(a.Cin / 8) * 2 * a.Mpad * 4;       // floats per tap
   const float* wlane = a.w + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + m0 + wq) * 4;
 
-  // Input window: item e = tid + 256 u -> (P = group*2 + h, col); its four K-steps are the
+  // Input window: item e = tid + NT u -> (P = group*2 + h, col); its four K-steps are the
   // channels 8 g + h + 2 s.  Offset of s = 0 inside a chunk, -1 = zero padding / masked.
   int xoff[NXP];
   {
@@ -118,46 +126,85 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
         }
       }
       xoff[u] = off;
-      col += 256;
-      if (col >= XL) { col -= XL; ++P; }
-      if (col >= XL) { col -= XL; ++P; }
+      col += NT;
+#pragma unroll
+      for (int w = 0; w < NT / 128; ++w)
+        if (col >= XL) { col -= XL; ++P; }
     }
   }
 
-  // One loop body, entered first with ci0 = -CK: issue(chunk 0) / skip compute / commit(chunk 0).
+  // Loop body, entered first with ci0 = -CK (no compute).  Single buffer (NWN == 2):
+  //   issue(c+1) | MFMA(c) | barrier | commit(c+1) | barrier
+  // Double buffer (NWN == 4): registers hold chunk c+1 on entry,
+  //   MFMA(c) from buf[c&1] | commit(c+1) -> buf[(c+1)&1] | issue(c+2) | barrier
+#define MBV_ISSUE(CN)                                                                        \
+  {                                                                                          \
+    const int cn_ = (CN);                                                                    \
+    const float* wchunk = wlane + (int64_t)(cn_ / 8) * 2 * a.Mpad * 4;                       \
+    _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
+      int64_t off;                                                                           \
+      if constexpr (RPI >= ROWS_PER_TAP) {                                                   \
+        int tap = wtap0 + u * (RPI / ROWS_PER_TAP); /* per-lane, clamped into the slab */    \
+        tap = tap < a.K ? tap : a.K - 1;                                                     \
+        off = (int64_t)(tap - wtap0) * tap_stride;                                           \
+      } else {                                                                               \
+        constexpr int PPT = ROWS_PER_TAP / RPI;      /* passes per tap */                    \
+        int tap = u / PPT;                           /* wave-uniform */                      \
+        tap = tap < a.K ? tap : a.K - 1;                                                     \
+        off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad * 4;                    \
+      }                                                                                      \
+      wreg[u] = *reinterpret_cast<const f32x4*>(wchunk + off);                               \
+    }                                                                                        \
+    const float* xchunk = xb + (int64_t)cn_ * a.x_rstride;                                   \
+    const unsigned rs2 = 2u * (unsigned)a.x_rstride;                                         \
+    _Pragma("unroll") for (int u = 0; u < NXP; ++u) {                                        \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                        \
+      if (xoff[u] >= 0) {                                                                    \
+        const unsigned o = (unsigned)xoff[u];                                                \
+        v[0] = xchunk[o]; v[1] = xchunk[o + rs2]; v[2] = xchunk[o + 2 * rs2]; v[3] = xchunk[o + 3 * rs2]; \
+      }                                                                                      \
+      xreg[u] = v;                                                                           \
+    }                                                                                        \
+  }
+#define MBV_COMMIT(CN, XS, WS)                                                               \
+  {                                                                                          \
+    const int cn_ = (CN);                                                                    \
+    _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
+      const int e = tid + NT * u;                                                            \
+      if (e < totalW) (WS)[e] = wreg[u];           /* LDS order == copy order */             \
+    }                                                                                        \
+    int P = tid / XL, col = tid - P * XL;                                                    \
+    _Pragma("unroll") for (int u = 0; u < NXP; ++u) {                                        \
+      if (P < 2 * G) {                                                                       \
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                      \
+        if (xoff[u] >= 0) {                                                                  \
+          v = xreg[u];                                                                       \
+          if (a.chan_add) {                                                                  \
+            const float* ca = a.chan_add + b * a.Cin + cn_ + (P >> 1) * 8 + (P & 1);         \
+            v[0] += ca[0]; v[1] += ca[2]; v[2] += ca[4]; v[3] += ca[6];                      \
+          }                                                                                  \
+          _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu(v[s4], a.in_slope); \
+        }                                                                                    \
+        (XS)[P * XL + col] = v;                                                              \
+      }                                                                                      \
+      col += NT;                                                                             \
+      _Pragma("unroll") for (int w = 0; w < NT / 128; ++w)                                   \
+        if (col >= XL) { col -= XL; ++P; }                                                   \
+    }                                                                                        \
+  }
+
+  const int nchunks = a.debug == 1 ? 1 : a.Cin / CK;          // debug 1: stage chunk 0 only (timing)
+  if constexpr (DB) { MBV_ISSUE(0); }
   for (int ci0 = -CK; ci0 < a.Cin; ci0 += CK) {
-    bool more = ci0 + CK < a.Cin;
-    if (a.debug == 1) more = ci0 < 0;                         // timing experiment: stage chunk 0 only
-    const int cn = ci0 + CK;                                  // chunk being prefetched
-    if (more) {
-      // ---- issue: weight slab and raw input window -> registers
-      const float* wchunk = wlane + (int64_t)(cn / 8) * 2 * a.Mpad * 4;
-#pragma unroll
-      for (int u = 0; u < NW; ++u) {
-        int64_t off;
-        if constexpr (RPI >= ROWS_PER_TAP) {
-          int tap = wtap0 + u * (RPI / ROWS_PER_TAP);        // per-lane, clamped to stay in the slab
-          tap = tap < a.K ? tap : a.K - 1;
-          off = (int64_t)(tap - wtap0) * tap_stride;
-        } else {
-          constexpr int PPT = ROWS_PER_TAP / RPI;            // passes per tap
-          int tap = u / PPT;                                 // wave-uniform
-          tap = tap < a.K ? tap : a.K - 1;
-          off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad * 4;
-        }
-        wreg[u] = *reinterpret_cast<const f32x4*>(wchunk + off);
-      }
-      const float* xchunk = xb + (int64_t)cn * a.x_rstride;
-      const unsigned rs2 = 2u * (unsigned)a.x_rstride;
-#pragma unroll
-      for (int u = 0; u < NXP; ++u) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (xoff[u] >= 0) {
-          const unsigned o = (unsigned)xoff[u];
-          v[0] = xchunk[o]; v[1] = xchunk[o + rs2]; v[2] = xchunk[o + 2 * rs2]; v[3] = xchunk[o + 3 * rs2];
-        }
-        xreg[u] = v;
-      }
+    const int c = ci0 / CK;                                   // -1 on the priming pass
+    const bool more = c + 1 < nchunks;                        // chunk c+1 exists
+    const int cn = ci0 + CK;
+    f32x4* const Xs = lds4 + (DB ? ((c & 1) ? buf_f4 : 0) : 0);           // buffer holding chunk c
+    f32x4* const Ws = Xs + G * 2 * XL;
+    f32x4* const Xn = lds4 + (DB ? ((c & 1) ? 0 : buf_f4) : 0);           // buffer for chunk c+1
+    f32x4* const Wn = Xn + G * 2 * XL;
+    if constexpr (!DB) {
+      if (more) { MBV_ISSUE(cn); }
     }
 
     if (ci0 >= 0 && a.debug != 3) {
@@ -224,37 +271,22 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
       }
     }
 
-    if (more) {
-      __syncthreads();            // every wave is done reading the previous chunk from LDS
-      // ---- commit: registers -> LDS, activation / conditioning applied on the way
-#pragma unroll
-      for (int u = 0; u < NW; ++u) {
-        const int e = tid + 256 * u;
-        if (e < totalW) Ws[e] = wreg[u];                     // LDS order == copy order
-      }
-      int P = tid / XL, col = tid - P * XL;
-#pragma unroll
-      for (int u = 0; u < NXP; ++u) {
-        if (P < 2 * G) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (xoff[u] >= 0) {
-            v = xreg[u];
-            if (a.chan_add) {
-              const float* ca = a.chan_add + b * a.Cin + cn + (P >> 1) * 8 + (P & 1);
-              v[0] += ca[0]; v[1] += ca[2]; v[2] += ca[4]; v[3] += ca[6];
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu(v[s4], a.in_slope);
-          }
-          Xs[P * XL + col] = v;
-        }
-        col += 256;
-        if (col >= XL) { col -= XL; ++P; }
-        if (col >= XL) { col -= XL; ++P; }
+    if constexpr (DB) {
+      if (more) {
+        MBV_COMMIT(cn, Xn, Wn);                   // other buffer: last read one barrier ago
+        if (c + 2 < nchunks) { MBV_ISSUE(cn + CK); }
       }
       __syncthreads();
+    } else {
+      if (more) {
+        __syncthreads();                          // every wave is done reading the buffer
+        MBV_COMMIT(cn, Xn, Wn);
+        __syncthreads();
+      }
     }
   }
+#undef MBV_ISSUE
+#undef MBV_COMMIT
 
   // ---- epilogue ----------------------------------------------------------
   // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -341,24 +373,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int WM, int WN, int CK>
+template <int WM, int WN, int CK, int NWN>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 64 * WN, G = CK / 8;
+  constexpr int BM = 64 * WM, BN = 32 * WN * NWN, G = CK / 8;
   const int XL = BN + (a.K - 1) * a.dil;
-  // float4 units: input image + weight slab + one step of padding for the operand prefetch overrun
-  const size_t lds_f4 = (size_t)G * 2 * XL + (size_t)a.K * G * 2 * BM + 2 * BM;
+  // float4 units per buffer: input image + weight slab + one step of padding for the operand
+  // prefetch overrun; two buffers for the 512-thread variant
+  const size_t buf_f4 = (size_t)G * 2 * XL + (size_t)a.K * G * 2 * BM + 2 * BM;
+  const size_t lds_bytes = buf_f4 * 16 * (NWN == 4 ? 2 : 1);
   dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
   ConvArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
   a2.debug = dbg;
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK>), grid, dim3(256), lds_f4 * 16, s, a2);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN>), grid, dim3(128 * NWN), lds_bytes, s, a2);
 }
 
 bool conv1d_supported(int K, int dil) {
   return K >= 1 && K <= 11 && (K - 1) * dil <= 72;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int NWN>
 static void launch_ck(const ConvArgs& a, hipStream_t s) {
   // chunk of input channels staged per LDS pass (register budget of the async stage:
   // CK=8: K <= 11, halo <= 72; CK=16: K <= 5, halo <= 24; CK=32: K == 1)
@@ -367,30 +407,28 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
     fprintf(stderr, "mbv: conv1d kernel size %d / dilation %d outside the built range\n", a.K, a.dil);
     abort();
   }
-  if (a.K == 1) launch_one<WM, WN, 32>(a, s);
-  else if (a.K <= 5 && halo <= 24) launch_one<WM, WN, 16>(a, s);
-  else launch_one<WM, WN, 8>(a, s);
+  if (a.K == 1) launch_one<WM, WN, 32, NWN>(a, s);
+  else if (a.K <= 5 && halo <= 24) launch_one<WM, WN, 16, NWN>(a, s);
+  else launch_one<WM, WN, 8, NWN>(a, s);
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
-  // Wave tile along time: 2 x 32 columns (block 128) or 3 x 32 (block 192, 6 accumulators per
-  // wave: ~6 % better matrix-pipe use) - whichever wastes fewer padded columns.
-  static const int widen = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
-  int wn = 2;
-  if (wide_m && widen >= 3 && a.T >= 192) {
-    const double eff2 = 0.94 * a.T / (double)(((a.T + 127) / 128) * 128);
-    const double eff3 = a.T / (double)(((a.T + 191) / 192) * 192);
-    // small launches: the longer 192-column blocks quantise badly over 2 blocks x 256 CUs
-    const long blocks3 = (long)((a.T + 191) / 192) * ((a.M + 127) / 128) * a.B;
-    if (eff3 >= eff2 && blocks3 >= 1024) wn = widen;
+  // Long sequences with enough blocks to fill the chip: 512-thread workgroups, 128 x 384 tile
+  // (6 accumulators per wave), double-buffered LDS.  Otherwise 256-thread, 128 x 128 tile.
+  static const int mode = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
+  bool big = false;
+  if (wide_m && mode >= 3 && a.T >= 384) {
+    const double eff2 = 0.90 * a.T / (double)(((a.T + 127) / 128) * 128);
+    const double eff3 = a.T / (double)(((a.T + 383) / 384) * 384);
+    const long blocks3 = (long)((a.T + 383) / 384) * ((a.M + 127) / 128) * a.B;
+    big = eff3 >= eff2 && blocks3 >= 512;
   }
   if (wide_m) {
-    if (wn == 4) launch_ck<2, 4>(a, s);
-    else if (wn == 3) launch_ck<2, 3>(a, s);
-    else launch_ck<2, 2>(a, s);
+    if (big) launch_ck<2, 3, 4>(a, s);
+    else launch_ck<2, 2, 2>(a, s);
   } else {
-    launch_ck<1, 2>(a, s);
+    launch_ck<1, 2, 2>(a, s);
   }
 }
 
