@@ -66,6 +66,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if os.environ.get("MBV_BENCH_ONE_DEVICE"):       # rehearsal: all ranks on cuda:0 (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -73,7 +75,11 @@ def main():
     from mb_istft_vits_amd import models, utils, synth, dist as mdist, spec as mspec
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("MBV_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     hps = utils.get_hparams_from_file(utils.builtin_config(args.config))
     net = models.SynthesizerTrn(59, hps.data.filter_length // 2 + 1,
