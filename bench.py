@@ -37,8 +37,8 @@ def decoder_flops_per_frame(cfg):
     rate = 1
     for i in range(2):
         cin, cout = C0 >> i, C0 >> (i + 1)
-        mac += cin * cout * 16 * rate            # ConvTranspose1d k16 s4: 4 taps per output, 4 outputs
-        rate *= 4
+        mac += cin * cout * 16 * rate            # ConvTranspose1d k16 stride u: 16/u taps x u outputs
+        rate *= cfg.upsample_rates[i]
         mac += sum(6 * k for k in cfg.resblock_kernel_sizes) * cout * cout * rate
     mac += (C0 >> 2) * cfg.post_channels * 7 * rate
     return 2.0 * mac

@@ -35,6 +35,7 @@ extern "C" {
 
 #define MBV_DEC_MULTIBAND   0   /* models.py:309 Multiband_iSTFT_Generator (fixed PQMF)        */
 #define MBV_DEC_MULTISTREAM 1   /* models.py:387 Multistream_iSTFT_Generator (trainable filter)*/
+#define MBV_DEC_SINGLEBAND  2   /* models.py:248 iSTFT_Generator (ups 8x8, no filter bank)      */
 
 typedef struct mbv_model mbv_model;   /* opaque */
 
@@ -52,7 +53,8 @@ typedef struct mbv_config {
   int32_t kernel_size;               /* FFN kernel, 3 */
   int32_t upsample_initial_channel;  /* 512 (mini: 256) */
   int32_t resblock_kernel_sizes[3];  /* 3,7,11 */
-  int32_t resblock_dilations[3][3];  /* 1,3,5 each */
+  int32_t resblock_dilations[3][3];  /* 1,3,5 each (ResBlock2: first two used) */
+  int32_t resblock_type;             /* 1 = ResBlock1 (modules.py:187), 2 = ResBlock2 (modules.py:237) */
   int32_t n_speakers;                /* 0 = single speaker */
   int32_t gin_channels;              /* 0 or 256 */
   int32_t decoder;                   /* MBV_DEC_* */
@@ -64,9 +66,9 @@ typedef struct mbv_config {
  * models.py:737).  T' = frames, F = 16 T' + 1, all device pointers. */
 typedef struct mbv_outputs {
   float *o;        /* [B, 1, 256 T']                         waveform           */
-  float *o_mb;     /* MB: [B, 4, 64 T'];  MS: [B, 4, 256 T'] (zero-stuffed)      */
-  float *spec;     /* [B, 4, 9, F]                                               */
-  float *phase;    /* [B, 4, 9, F]                                               */
+  float *o_mb;     /* MB: [B, 4, 64 T'];  MS: [B, 4, 256 T'] (zero-stuffed); SB: unused */
+  float *spec;     /* [B, 4, 9, F]      (SB: [B, 9, F] with F = 64 T' + 1)      */
+  float *phase;    /* same shape as spec                                         */
   float *attn;     /* [B, 1, T', T]                          (synthesize only)   */
   float *y_mask;   /* [B, 1, T']                             (synthesize only)   */
   float *z;        /* [B, 192, T']                           (synthesize only)   */

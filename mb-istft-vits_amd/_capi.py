@@ -27,6 +27,7 @@ class MbvConfig(C.Structure):
         ("n_layers", C.c_int32), ("kernel_size", C.c_int32),
         ("upsample_initial_channel", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilations", (C.c_int32 * 3) * 3),
+        ("resblock_type", C.c_int32),
         ("n_speakers", C.c_int32), ("gin_channels", C.c_int32), ("decoder", C.c_int32),
         ("device", C.c_int32),
     ]

@@ -78,6 +78,7 @@ struct mbv_model {
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
   bool user_tab_is_pqmf = false;
   int xpost_F = 1;             // frames per row of the last x_post stage tensor
+  int xpost_rows = 72;         // 72 (4 bands x 18) or 18 (single band)
   int exact_math = 0;          // MBV_ISTFT_EXACT=1: libm transcendentals in the iSTFT kernel
 
   // state of the last encode
@@ -144,6 +145,9 @@ void build_expected(mbv_model* m) {
   add_key(m, "dec.conv_pre.bias", {C0});
   add_key(m, "dec.conv_pre.weight_g", {C0, 1, 1});
   add_key(m, "dec.conv_pre.weight_v", {C0, I, 7});
+  const bool sb = c.decoder == MBV_DEC_SINGLEBAND;
+  const int post_rows = sb ? 18 : 72;
+  const char* post_name = sb ? "dec.conv_post" : "dec.subband_conv_post";
   for (int i = 0; i < 2; ++i) {
     const int cin = C0 >> i, cout = C0 >> (i + 1);
     snprintf(p, sizeof p, "dec.ups.%d.", i);
@@ -155,13 +159,17 @@ void build_expected(mbv_model* m) {
     const int ch = C0 >> (i + 1);
     for (int j = 0; j < 3; ++j) {
       const int k = c.resblock_kernel_sizes[j];
-      for (const char* grp : {"convs1", "convs2"})
-        for (int q = 0; q < 3; ++q) {
+      const bool rb1 = c.resblock_type == 1;
+      for (const char* grp : {"convs1", "convs2", "convs"}) {
+        const bool is2 = std::strcmp(grp, "convs") == 0;
+        if (is2 == rb1) continue;                      // ResBlock1: convs1/convs2 x3, ResBlock2: convs x2
+        for (int q = 0; q < (rb1 ? 3 : 2); ++q) {
           snprintf(p, sizeof p, "dec.resblocks.%d.%s.%d.", i * 3 + j, grp, q);
           add_key(m, std::string(p) + "bias", {ch});
           add_key(m, std::string(p) + "weight_g", {ch, 1, 1});
           add_key(m, std::string(p) + "weight_v", {ch, ch, k});
         }
+      }
       if (gin) {
         snprintf(p, sizeof p, "dec.resblocks.%d.cond.", i * 3 + j);
         add_key(m, std::string(p) + "weight", {ch, gin, 1});
@@ -169,9 +177,9 @@ void build_expected(mbv_model* m) {
       }
     }
   }
-  add_key(m, "dec.subband_conv_post.bias", {72});
-  add_key(m, "dec.subband_conv_post.weight_g", {72, 1, 1});
-  add_key(m, "dec.subband_conv_post.weight_v", {72, C0 >> 2, 7});
+  add_key(m, std::string(post_name) + ".bias", {post_rows});
+  add_key(m, std::string(post_name) + ".weight_g", {post_rows, 1, 1});
+  add_key(m, std::string(post_name) + ".weight_v", {post_rows, C0 >> 2, 7});
   if (c.decoder == MBV_DEC_MULTISTREAM) {
     add_key(m, "dec.multistream_conv_post.weight_g", {1, 1, 1});
     add_key(m, "dec.multistream_conv_post.weight_v", {1, 4, 63});
@@ -466,22 +474,31 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
     auto& U = m->ups[i];
     U.Cin = (int)sh[0]; U.Cout = (int)sh[1]; U.Mpad = (int)align_up(U.Cout, 64);
     U.w = P.alloc((size_t)16 * U.Cin * U.Mpad);
-    for (int r = 0; r < 4; ++r)
-      for (int j = 0; j < 4; ++j) {
-        const int k = (r + 2) % 4 + 4 * j;
+    const int us = c.decoder == MBV_DEC_SINGLEBAND ? 8 : 4;        // stride; k = 16, pad = (16-us)/2
+    const int tpp = 16 / us, pad = (16 - us) / 2;
+    for (int r = 0; r < us; ++r)
+      for (int j = 0; j < tpp; ++j) {
+        const int k = (r + pad) % us + us * j;
         for (int ci = 0; ci < U.Cin; ++ci) {
-          float* dst = &arena[U.w + ((size_t)(r * 4 + j) * U.Cin + ci) * U.Mpad];
+          float* dst = &arena[U.w + ((size_t)(r * tpp + j) * U.Cin + ci) * U.Mpad];
           for (int co = 0; co < U.Cout; ++co) dst[co] = w[((size_t)ci * U.Cout + co) * 16 + k];
         }
       }
     U.bias = P.vec(std::string(p) + ".bias").off;
   }
   for (int n = 0; n < 6; ++n) {
-    for (int q = 0; q < 3; ++q) {
-      snprintf(p, sizeof p, "dec.resblocks.%d.convs1.%d", n, q);
-      m->rb[n].c1[q] = P.conv_plain(p);
-      snprintf(p, sizeof p, "dec.resblocks.%d.convs2.%d", n, q);
-      m->rb[n].c2[q] = P.conv_plain(p);
+    if (c.resblock_type == 1) {
+      for (int q = 0; q < 3; ++q) {
+        snprintf(p, sizeof p, "dec.resblocks.%d.convs1.%d", n, q);
+        m->rb[n].c1[q] = P.conv_plain(p);
+        snprintf(p, sizeof p, "dec.resblocks.%d.convs2.%d", n, q);
+        m->rb[n].c2[q] = P.conv_plain(p);
+      }
+    } else {
+      for (int q = 0; q < 2; ++q) {
+        snprintf(p, sizeof p, "dec.resblocks.%d.convs.%d", n, q);
+        m->rb[n].c1[q] = P.conv_plain(p);
+      }
     }
     if (gin) {
       snprintf(p, sizeof p, "dec.resblocks.%d.cond.", n);
@@ -491,9 +508,10 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
   }
   {   // subband_conv_post, rows pre-scaled for the fused iSTFT kernel: exp(x) = 2^(x log2 e),
       // sin(x) = sin_turns(x / 2 pi)  (istft_pqmf.hip, template PRE)
-    std::vector<float> w = P.dense("dec.subband_conv_post");
-    std::vector<float> bsc = P.t("dec.subband_conv_post.bias").data;
-    const auto& sh = P.t("dec.subband_conv_post.weight_v").shape;
+    const std::string pn = c.decoder == MBV_DEC_SINGLEBAND ? "dec.conv_post" : "dec.subband_conv_post";
+    std::vector<float> w = P.dense(pn);
+    std::vector<float> bsc = P.t(pn + ".bias").data;
+    const auto& sh = P.t(pn + ".weight_v").shape;
     const int Cout = (int)sh[0], Cin = (int)sh[1], K = (int)sh[2];
     for (int co = 0; co < Cout; ++co) {
       const float sc = (co % 18) < 9 ? 1.44269504088896341f : 0.15915494309189535f;
@@ -507,7 +525,7 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
   if (c.decoder == MBV_DEC_MULTISTREAM) {
     const std::vector<float> h = P.dense("dec.multistream_conv_post");   // [1][4][63]
     m->filt = P.vec_data(synthesis_table(h.data()));
-  } else {
+  } else if (c.decoder == MBV_DEC_MULTIBAND) {
     const std::vector<float> h = pqmf_synthesis_filter();
     m->filt = P.vec_data(synthesis_table(h.data()));
   }
@@ -575,9 +593,11 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   const float* cur = x0;
   int L = Td;
   float* xs = nullptr;
+  const bool sb = c.decoder == MBV_DEC_SINGLEBAND;
+  const int us = sb ? 8 : 4;                       // upsample stride of both stages
   for (int i = 0; i < 2; ++i) {
     const int ch = C0 >> (i + 1);
-    const int Lo = 4 * L;
+    const int Lo = us * L;
     const size_t n = (size_t)B * ch * Lo;
     float* u = sc.take<float>(n);
     float* t1 = sc.take<float>(n);
@@ -588,7 +608,8 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       a.x = cur; a.w = m->W(m->ups[i].w); a.bias = m->W(m->ups[i].bias); a.y = u;
       a.B = B; a.Cin = m->ups[i].Cin; a.Cout = ch; a.Mpad = m->ups[i].Mpad; a.Tin = L;
       a.in_slope = kLrelu;
-      launch_convt4(a, s);
+      a.stride = us;
+      launch_convt(a, s);
     }
     m->stages[i == 0 ? "dec_up_0" : "dec_up_1"] = {u, (int64_t)n};
     for (int j = 0; j < 3; ++j) {
@@ -600,6 +621,27 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
         cadd = cb;
       }
       const float* state = u;
+      if (c.resblock_type == 2) {
+        // ResBlock2 (modules.py:251-262): x = conv_d(lrelu(x)) + x for d in dilations
+        for (int q = 0; q < 2; ++q) {
+          const int d = c.resblock_dilations[j][q];
+          ConvArgs a = conv_args(m, R.c1[q], state, (int64_t)ch * Lo, Lo, r, (int64_t)ch * Lo, Lo, B, d);
+          a.in_slope = kLrelu;
+          a.res = state; a.res_bstride = (int64_t)ch * Lo;
+          if (q == 0) { a.chan_add = cadd; a.res_chan_add = cadd; }
+          if (q == 0) {
+            a.epi = EPI_RESID;
+          } else {
+            a.epi = EPI_RESID_ACC;
+            a.y = xs;
+            a.accum_in = j == 0 ? nullptr : xs;
+            a.out_scale = j == 2 ? (1.f / 3.f) : 1.f;
+          }
+          launch_conv1d(a, s);
+          state = r;
+        }
+        continue;
+      }
       for (int q = 0; q < 3; ++q) {
         const int d = c.resblock_dilations[j][q];
         {
@@ -632,28 +674,37 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   }
   const int Fr = L + 1;
   const int chl = C0 >> 2;
-  if ((int64_t)B * 72 * Fr * 4 >= (1LL << 31))
+  const int prow = sb ? 18 : 72;
+  if ((int64_t)B * prow * Fr * 4 >= (1LL << 31))
     return m->fail("batch x frames too large for one launch (x_post must stay below 2 GiB): split the batch");
-  float* xpost = sc.take<float>((size_t)B * 72 * Fr);
+  float* xpost = sc.take<float>((size_t)B * prow * Fr);
   {
-    ConvArgs a = conv_args(m, m->conv_post, cur, (int64_t)chl * L, L, xpost, (int64_t)72 * Fr, Fr, B);
+    ConvArgs a = conv_args(m, m->conv_post, cur, (int64_t)chl * L, L, xpost, (int64_t)prow * Fr, Fr, B);
     a.in_slope = 0.01f;                              // F.leaky_relu default slope (models.py:363)
     a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
     launch_conv1d(a, s);
   }
-  m->stages["x_post"] = {xpost, (int64_t)B * 72 * Fr};
+  m->stages["x_post"] = {xpost, (int64_t)B * prow * Fr};
   m->xpost_F = Fr;
+  m->xpost_rows = prow;
   float* o = outs ? outs->o : nullptr;
   float* otmp = nullptr;
   if (!o) { otmp = sc.take<float>((size_t)B * 256 * Td); o = otmp; }
-  IstftArgs ia{};
-  ia.x_post = xpost; ia.filt = m->W(m->filt.off); ia.o = o;
-  ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
-  ia.phase = outs ? outs->phase : nullptr;
-  ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
-  ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
   HIPCHK(m, hipEventRecord(m->evk[1], s));
-  launch_istft_pqmf(ia, s);
+  if (sb) {
+    IstftSbArgs ia{};
+    ia.x_post = xpost; ia.o = o; ia.spec = outs ? outs->spec : nullptr; ia.phase = outs ? outs->phase : nullptr;
+    ia.B = B; ia.F = Fr; ia.exact_math = m->exact_math; ia.prescaled = 1;
+    launch_istft_single(ia, s);
+  } else {
+    IstftArgs ia{};
+    ia.x_post = xpost; ia.filt = m->W(m->filt.off); ia.o = o;
+    ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
+    ia.phase = outs ? outs->phase : nullptr;
+    ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
+    ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
+    launch_istft_pqmf(ia, s);
+  }
   HIPCHK(m, hipEventRecord(m->evk[2], s));
   m->evk_set = true;
   return 0;
@@ -661,9 +712,10 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
 
 size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td) {
   const size_t C0 = c.upsample_initial_channel;
+  const size_t us = c.decoder == MBV_DEC_SINGLEBAND ? 8 : 4;
   size_t n = (size_t)B * C0 * Td;                              // conv_pre
-  n += 4 * (size_t)B * (C0 / 2) * 4 * Td + 4 * (size_t)B * (C0 / 4) * 16 * Td;
-  n += (size_t)B * 72 * (16 * Td + 1) + (size_t)B * 256 * Td;
+  n += 4 * (size_t)B * (C0 / 2) * us * Td + 4 * (size_t)B * (C0 / 4) * us * us * Td;
+  n += (size_t)B * 72 * (us * us * Td + 1) + (size_t)B * 256 * Td;
   n += 6 * (size_t)B * C0;                                     // cond vectors
   return n * sizeof(float) + 64 * 256;
 }
@@ -693,13 +745,16 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
       cfg->hidden_channels / cfg->n_heads > 128)
     return bad("hidden_channels / n_heads must be an even integer <= 128");
   if (cfg->upsample_initial_channel % 128) return bad("upsample_initial_channel must be a multiple of 128");
-  if (cfg->decoder != MBV_DEC_MULTIBAND && cfg->decoder != MBV_DEC_MULTISTREAM) return bad("unknown decoder");
+  if (cfg->decoder != MBV_DEC_MULTIBAND && cfg->decoder != MBV_DEC_MULTISTREAM &&
+      cfg->decoder != MBV_DEC_SINGLEBAND)
+    return bad("unknown decoder");
   if (cfg->n_speakers > 1 && cfg->gin_channels <= 0) return bad("n_speakers > 1 needs gin_channels > 0");
   for (int j = 0; j < 3; ++j)
     if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0)
       return bad("resblock kernel sizes must be odd");
+  if (cfg->resblock_type != 1 && cfg->resblock_type != 2) return bad("resblock_type must be 1 or 2");
   for (int j = 0; j < 3; ++j)
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < (cfg->resblock_type == 1 ? 3 : 2); ++q)
       if (cfg->resblock_dilations[j][q] < 1 ||
           !conv1d_supported(cfg->resblock_kernel_sizes[j], cfg->resblock_dilations[j][q]))
         return bad("resblock kernel size / dilation outside the built range (k <= 11, (k-1)*d <= 72)");
@@ -1061,7 +1116,7 @@ int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capac
   if (!dst) return numel;
   if (capacity < numel) { m->fail("capacity too small"); return -1; }
   if (n == "x_post") {     // stored pre-scaled for the iSTFT kernel: hand back the reference's units
-    launch_unscale_xpost(src, dst, (int)(numel / (72 * (int64_t)m->xpost_F)), m->xpost_F, (hipStream_t)stream);
+    launch_unscale_xpost(src, dst, (int)(numel / (m->xpost_rows * (int64_t)m->xpost_F)), m->xpost_rows, m->xpost_F, (hipStream_t)stream);
     return numel;
   }
   if (hipMemcpyAsync(dst, src, numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {

@@ -433,19 +433,23 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
 }
 
 // ============================================================================
-// ConvTranspose1d(k=16, stride=4, padding=6) — models.py:321-323, 352.
-// Polyphase form: output phase r = t mod 4 of frame m = t / 4 is a 4-tap conv
-//   y[co, 4m+r] = bias + sum_ci sum_j W[ci][co][kr + 4j] * act(x[ci, m + sh - j])
-//   kr = (r+2)%4, sh = 1 (r<2) or 2 (r>=2)
-// All four phases share the input window x[m-2 .. m+2]; one wave accumulates the
-// four phase tiles of a (32 co x 32 m) patch so each lane ends up owning four
-// consecutive output samples -> one 16-byte store per lane.
+// ConvTranspose1d(k=16, stride=U, padding=(16-U)/2), U in {4, 8} — models.py:321-323 (mb/ms: 4),
+// models.py:264-267 (single-band iSTFT_Generator: 8).
+// Polyphase form: output phase r = t mod U of frame m = t / U is a (16/U)-tap conv
+//   y[co, U m + r] = bias + sum_ci sum_j W[ci][co][kr + U j] * act(x[ci, m + sh_r - j])
+//   kr = (r + p) % U, sh_r = (r + p - kr) / U   (p = padding)
+// All phases share the input window x[m + sh_0 - (TPP-1) .. m + sh_0 + 1]; one wave accumulates
+// the U phase tiles of a (32 co x 32 m) patch, so each lane ends up owning U consecutive output
+// samples -> 16-byte stores.
 // ============================================================================
-template <int CK>
-__global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
-  constexpr int BMc = 64;    // output channels per block
-  constexpr int BNm = 64;    // input frames per block
-  constexpr int XS = BNm + 4;
+template <int U, int CK>
+__global__ __launch_bounds__(256) void convt_mfma_kernel(const ConvTArgs a) {
+  constexpr int TPP = 16 / U;                 // taps per phase
+  constexpr int PAD = (16 - U) / 2;
+  constexpr int SH0 = PAD / U;                // sh_r of phase 0 (phases with kr wrapped get SH0 + 1)
+  constexpr int BMc = 64;                     // output channels per block
+  constexpr int BNm = 64;                     // input frames per block
+  constexpr int XS = BNm + TPP;
   __shared__ __attribute__((aligned(16))) float Xs[CK * XS];
   __shared__ __attribute__((aligned(16))) float Ws[16 * CK * BMc];
 
@@ -453,9 +457,9 @@ __global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
   const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, co0 = blockIdx.y * BMc, mb0 = blockIdx.x * BNm;
 
-  f32x16 acc[4];
+  f32x16 acc[U];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < U; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
     __syncthreads();
     for (int e = tid; e < CK * XS; e += 256) {
       const int r = e / XS, c = e % XS;
-      const int n = mb0 - 2 + c;
+      const int n = mb0 + SH0 - (TPP - 1) + c;
       float v = 0.f;
       if (n >= 0 && n < a.Tin) v = lrelu(xb[(int64_t)(ci0 + r) * a.Tin + n], a.in_slope);
       Xs[e] = v;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
     {
       constexpr int Q = BMc / 4;
       for (int e = tid; e < 16 * CK * Q; e += 256) {
-        const int row = e / Q, q = e % Q;      // row = (r*4 + j)*CK + c
+        const int row = e / Q, q = e % Q;      // row = (r*TPP + j)*CK + c
         const int rj = row / CK, c = row % CK;
         const float4* src = reinterpret_cast<const float4*>(
             a.w + ((int64_t)rj * a.Cin + ci0 + c) * a.Mpad + co0) + q;
@@ -485,45 +489,46 @@ __global__ __launch_bounds__(256) void convt4_mfma_kernel(const ConvTArgs a) {
       const float* xrow = Xs + (2 * c2 + hl) * XS + wn * 32 + l31;
       const float* wbase = Ws + (2 * c2 + hl) * BMc + wm * 32 + l31;
 #pragma unroll
-      for (int tau = 0; tau < 5; ++tau) {
+      for (int tau = 0; tau <= TPP; ++tau) {
         const float bv = xrow[tau];
-        if (tau <= 3) {
-          const int j = 3 - tau;
-          const float a0 = wbase[((0 * 4 + j) * CK) * BMc];
-          const float a1 = wbase[((1 * 4 + j) * CK) * BMc];
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
-        }
-        if (tau >= 1) {
-          const int j = 4 - tau;
-          const float a2 = wbase[((2 * 4 + j) * CK) * BMc];
-          const float a3 = wbase[((3 * 4 + j) * CK) * BMc];
-          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv, acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bv, acc[3], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          constexpr int dummy = 0; (void)dummy;
+          const int sh = ((r + PAD) - ((r + PAD) % U)) / U - SH0;   // 0 or 1 (compile-time after unroll)
+          const int j = sh + TPP - 1 - tau;
+          if (j >= 0 && j < TPP) {
+            const float av = wbase[((r * TPP + j) * CK) * BMc];
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r], 0, 0, 0);
+          }
         }
       }
     }
   }
   const int m = mb0 + wn * 32 + l31;
   if (m < a.Tin) {
-    const int Tout = 4 * a.Tin;
+    const int Tout = U * a.Tin;
     float* yb = a.y + (int64_t)b * a.Cout * Tout;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
       if (co < a.Cout) {
         const float bias = a.bias ? a.bias[co] : 0.f;
-        float4 o;
-        o.x = acc[0][r] + bias; o.y = acc[1][r] + bias; o.z = acc[2][r] + bias; o.w = acc[3][r] + bias;
-        *reinterpret_cast<float4*>(yb + (int64_t)co * Tout + 4 * m) = o;
+#pragma unroll
+        for (int q = 0; q < U / 4; ++q) {
+          float4 o;
+          o.x = acc[4 * q + 0][r] + bias; o.y = acc[4 * q + 1][r] + bias;
+          o.z = acc[4 * q + 2][r] + bias; o.w = acc[4 * q + 3][r] + bias;
+          *reinterpret_cast<float4*>(yb + (int64_t)co * Tout + U * m + 4 * q) = o;
+        }
       }
     }
   }
 }
 
-void launch_convt4(const ConvTArgs& a, hipStream_t s) {
+void launch_convt(const ConvTArgs& a, hipStream_t s) {
   dim3 grid((a.Tin + 63) / 64, (a.Cout + 63) / 64, a.B);
-  hipLaunchKernelGGL((convt4_mfma_kernel<8>), grid, dim3(256), 0, s, a);
+  if (a.stride == 8) hipLaunchKernelGGL((convt_mfma_kernel<8, 8>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((convt_mfma_kernel<4, 8>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace mbv

@@ -350,4 +350,80 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
 #undef MBV_ISTFT_LAUNCH
 }
 
+// ============================================================================
+// Single-band tail of iSTFT_Generator (models.py:296-300): exp / pi*sin, TorchSTFT.inverse
+// (n_fft 16, hop 4), no filter bank.  Phase A: one lane per frame (255 frames per workgroup);
+// phase B: one lane per quad of output samples (252 quads): overlap-add of the 4 covering
+// frames, edge-aware envelope, one 16-byte store.
+// ============================================================================
+template <bool FAST, bool PRE>
+__global__ __launch_bounds__(256) void istft_single_kernel(const IstftSbArgs a, int tiles_per_utt) {
+  constexpr int QPB = 252;                 // output quads per workgroup
+  constexpr int NFS = 256;
+  __shared__ float fr[16 * NFS];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_per_utt;
+  const int q0 = (blockIdx.x % tiles_per_utt) * QPB;
+  const int F = a.F;
+  const int nquads = F - 1;                // 4 (F-1) output samples
+
+  {
+    const int f = q0 - 1 + tid;
+    float out[16];
+    if (tid < QPB + 3 && f >= 0 && f < F) {
+      const float* xp = a.x_post + (int64_t)b * 18 * F + f;
+      float xin[18];
+#pragma unroll
+      for (int k = 0; k < 18; ++k) xin[k] = xp[(int64_t)k * F];
+      float re[9], im[9];
+      const bool own = f >= q0 && (f < q0 + QPB || f == F - 1);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float mag, ph;
+        polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
+        if (own) {
+          if (a.spec) a.spec[((int64_t)b * 9 + k) * F + f] = mag;
+          if (a.phase) a.phase[((int64_t)b * 9 + k) * F + f] = ph;
+        }
+      }
+      irfft16_hann(re, im, out);
+    } else {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) out[n] = 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < 16; ++n) fr[n * NFS + tid] = out[n];
+  }
+  __syncthreads();
+  const int fp = q0 + tid;                 // quad f': samples 4 f' + r from frames f'-1 .. f'+2
+  if (tid < QPB && fp < nquads) {
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sacc = 0.f, env = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = fp - 1 + g;
+        sacc += fr[(12 - 4 * g + r) * NFS + tid + g];
+        env += (f >= 0 && f < F) ? HANN16[12 - 4 * g + r] * HANN16[12 - 4 * g + r] : 0.f;
+      }
+      y[r] = sacc / env;
+    }
+    *reinterpret_cast<float4*>(a.o + (int64_t)b * 4 * nquads + 4 * (int64_t)fp) =
+        make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
+void launch_istft_single(const IstftSbArgs& a, hipStream_t s) {
+  const int tiles = (a.F - 1 + 251) / 252;
+  const dim3 grid(tiles * a.B), block(256);
+  const int variant = (a.exact_math ? 0 : 2) | (a.prescaled ? 1 : 0);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((istft_single_kernel<false, false>), grid, block, 0, s, a, tiles); break;
+    case 1: hipLaunchKernelGGL((istft_single_kernel<false, true>), grid, block, 0, s, a, tiles); break;
+    case 2: hipLaunchKernelGGL((istft_single_kernel<true, false>), grid, block, 0, s, a, tiles); break;
+    default: hipLaunchKernelGGL((istft_single_kernel<true, true>), grid, block, 0, s, a, tiles); break;
+  }
+}
+
 }  // namespace mbv

@@ -62,17 +62,19 @@ struct ConvArgs {
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
 
-// ---------------------------------------------------------------- ConvTranspose1d k=16 s=4 p=6 (MFMA)
-// Packed: Wt[r][j][Cin][Mpad] with Wt[r][j][ci][co] = W[ci][co][(r+2)%4 + 4j]
+// ---------------------------------------------------------------- ConvTranspose1d k=16, stride 4 / 8 (MFMA)
+// Packed: Wt[r][j][Cin][Mpad] with Wt[r][j][ci][co] = W[ci][co][(r + pad) % stride + stride * j],
+// r < stride, j < 16 / stride, pad = (16 - stride) / 2
 struct ConvTArgs {
   const float* x;     // [B, Cin, Tin]
   const float* w;     // packed
   const float* bias;  // [Cout]
-  float* y;           // [B, Cout, 4*Tin]
+  float* y;           // [B, Cout, stride*Tin]
   int B, Cin, Cout, Mpad, Tin;
   float in_slope;
+  int stride;         // 4 or 8
 };
-void launch_convt4(const ConvTArgs& a, hipStream_t s);
+void launch_convt(const ConvTArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- text encoder pieces
 void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
@@ -119,8 +121,19 @@ struct IstftArgs {
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
 
+// single-band iSTFT (iSTFT_Generator, models.py:296-300): x_post [B, 18, F] -> o [B, 4 (F-1)]
+struct IstftSbArgs {
+  const float* x_post;   // [B, 18, F]
+  float* o;              // [B, 4 (F - 1)]
+  float* spec;           // [B, 9, F] or null
+  float* phase;          // [B, 9, F] or null
+  int B, F;
+  int exact_math, prescaled;
+};
+void launch_istft_single(const IstftSbArgs& a, hipStream_t s);
+
 // x_post rows back to the reference's units (stage introspection): inverse of the pre-scaling
-void launch_unscale_xpost(const float* src, float* dst, int B, int F, hipStream_t s);
+void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, hipStream_t s);
 
 // misc
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);

@@ -264,20 +264,20 @@ void launch_gather_rows(const float* table, const int64_t* sid, float* out, int 
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(128), 0, s, table, sid, out, C, n_rows);
 }
 
-__global__ void unscale_xpost_kernel(const float* src, float* dst, int F, int64_t n) {
+__global__ void unscale_xpost_kernel(const float* src, float* dst, int rows, int F, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    const int ch = (int)((i / F) % 72);
+    const int ch = (int)((i / F) % rows);
     dst[i] = src[i] * ((ch % 18) < 9 ? 0.69314718055994531f : 6.28318530717958648f);
   }
 }
 
-void launch_unscale_xpost(const float* src, float* dst, int B, int F, hipStream_t s) {
-  const int64_t n = (int64_t)B * 72 * F;
+void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, hipStream_t s) {
+  const int64_t n = (int64_t)B * rows * F;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(unscale_xpost_kernel, dim3(blocks), dim3(256), 0, s, src, dst, F, n);
+  hipLaunchKernelGGL(unscale_xpost_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, F, n);
 }
 
 __global__ void fill_kernel(float* p, float v, int64_t n) {

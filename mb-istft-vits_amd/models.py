@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import _capi
-from .spec import ModelConfig, config_from_ctor, param_shapes, DEC_MS
+from .spec import ModelConfig, config_from_ctor, param_shapes, DEC_MS, DEC_SB
 
 _STAGES = ("text_encoder", "duration_predictor", "alignment_and_projection", "flow",
            "waveform_decoder")
@@ -182,10 +182,11 @@ class SynthesizerTrn(nn.Module):
             c.kernel_size, c.upsample_initial_channel = cfg.kernel_size, cfg.upsample_initial_channel
             for j in range(3):
                 c.resblock_kernel_sizes[j] = cfg.resblock_kernel_sizes[j]
-                for q in range(3):
-                    c.resblock_dilations[j][q] = cfg.resblock_dilation_sizes[j][q]
+                for q, d in enumerate(cfg.resblock_dilation_sizes[j]):
+                    c.resblock_dilations[j][q] = d
+            c.resblock_type = int(cfg.resblock)
             c.n_speakers, c.gin_channels = cfg.n_speakers, cfg.gin_channels
-            c.decoder = 1 if cfg.decoder == DEC_MS else 0
+            c.decoder = int(cfg.decoder)
             c.device = idx
             h = C.c_void_p()
             rc = L.mbv_create(C.byref(c), C.byref(h))
@@ -289,8 +290,8 @@ class SynthesizerTrn(nn.Module):
                 if Td <= 0:
                     raise ValueError("max_len leaves no frames to decode")
                 o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Td, dev)
-                out.o, out.o_mb, out.spec, out.phase = (o.data_ptr(), o_mb.data_ptr(),
-                                                        spec.data_ptr(), phase.data_ptr())
+                out.o, out.spec, out.phase = o.data_ptr(), spec.data_ptr(), phase.data_ptr()
+                out.o_mb = o_mb.data_ptr() if o_mb is not None else None
             self._ticket += 1
             _capi.check(h, L.mbv_synthesize(h, Tp, self._ptr(noise), float(noise_scale),
                                             int(Td if max_len is not None else 0), C.byref(out), stream),
@@ -302,6 +303,9 @@ class SynthesizerTrn(nn.Module):
         f32 = dict(device=dev, dtype=torch.float32)
         spf = self.cfg.samples_per_frame
         o = torch.empty(B, 1, spf * Td, **f32)
+        if self.cfg.decoder == DEC_SB:                         # models.py:300: (out, None, spec, phase)
+            Fr = 64 * Td + 1
+            return o, None, torch.empty(B, 9, Fr, **f32), torch.empty(B, 9, Fr, **f32)
         if self.cfg.decoder == DEC_MS:
             o_mb = torch.empty(B, 4, spf * Td, **f32)         # zero-stuffed (models.py:463)
         else:
@@ -346,7 +350,8 @@ class SynthesizerTrn(nn.Module):
         with torch.cuda.device(dev):
             o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Tp, dev)
             out = _capi.MbvOutputs()
-            out.o, out.o_mb, out.spec, out.phase = o.data_ptr(), o_mb.data_ptr(), spec.data_ptr(), phase.data_ptr()
+            out.o, out.spec, out.phase = o.data_ptr(), spec.data_ptr(), phase.data_ptr()
+            out.o_mb = o_mb.data_ptr() if o_mb is not None else None
             _capi.check(h, _capi.lib().mbv_decode(h, self._ptr(z), self._ptr(g), B, Tp, C.byref(out),
                                                   self._stream()), "mbv_decode")
         return o, o_mb, spec, phase

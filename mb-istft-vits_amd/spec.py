@@ -13,6 +13,7 @@ from typing import List, Tuple
 # decoder families, `models.py:634-644`
 DEC_MB = 0   # Multiband_iSTFT_Generator  (fixed PQMF synthesis)
 DEC_MS = 1   # Multistream_iSTFT_Generator (trainable synthesis filter)
+DEC_SB = 2   # iSTFT_Generator (single band, ups 8x8, no filter bank)
 
 WINDOW_SIZE = 4          # attentions.py:14 (Encoder default, never overridden)
 DP_FILTER = 256          # models.py:652
@@ -70,21 +71,28 @@ class ModelConfig:
 
     def validate(self):
         """Reject configurations the HIP path does not implement, loudly."""
-        if self.resblock != "1":
-            raise ValueError("only resblock='1' (ResBlock1, modules.py:187) is implemented; "
-                             "every reference config uses it")
-        if self.upsample_rates != [4, 4] or self.upsample_kernel_sizes != [16, 16]:
-            raise ValueError("decoder upsampling must be rates [4,4] kernels [16,16] "
-                             "(all mb/ms configs); got %r %r" %
-                             (self.upsample_rates, self.upsample_kernel_sizes))
-        if self.gen_istft_n_fft != 16 or self.gen_istft_hop_size != 4 or self.subbands != 4:
-            raise ValueError("iSTFT+PQMF kernel is built for n_fft=16 hop=4 subbands=4")
+        if self.resblock not in ("1", "2"):
+            raise ValueError("resblock must be '1' (ResBlock1, modules.py:187) or '2' (ResBlock2, "
+                             "modules.py:237)")
+        want = 3 if self.resblock == "1" else 2
+        if len(self.resblock_kernel_sizes) != 3 or any(len(d) != want for d in self.resblock_dilation_sizes):
+            raise ValueError("resblock '%s' needs 3 kernel sizes with %d dilations each" %
+                             (self.resblock, want))
+        want_rates = [8, 8] if self.decoder == DEC_SB else [4, 4]
+        if self.upsample_rates != want_rates or self.upsample_kernel_sizes != [16, 16]:
+            raise ValueError("decoder upsampling must be rates %r kernels [16,16] for this decoder "
+                             "(every reference config of the family); got %r %r" %
+                             (want_rates, self.upsample_rates, self.upsample_kernel_sizes))
+        if self.gen_istft_n_fft != 16 or self.gen_istft_hop_size != 4 or \
+                self.subbands != (1 if self.decoder == DEC_SB else 4):
+            raise ValueError("the iSTFT kernels are built for n_fft=16 hop=4 and 4 sub-bands "
+                             "(mb/ms) or 1 (istft_vits)")
         if self.hidden_channels % self.n_heads:
             raise ValueError("hidden_channels must divide by n_heads (attentions.py:104)")
         if self.inter_channels % 2:
             raise ValueError("channels should be divisible by 2 (modules.py:318)")
-        if self.decoder not in (DEC_MB, DEC_MS):
-            raise ValueError("decoder must be mb_istft_vits or ms_istft_vits")
+        if self.decoder not in (DEC_MB, DEC_MS, DEC_SB):
+            raise ValueError("decoder must be mb_istft_vits, ms_istft_vits or istft_vits")
         for c in (self.hidden_channels, self.inter_channels, self.filter_channels,
                   self.upsample_initial_channel // 4):
             if c % 32:
@@ -109,8 +117,7 @@ def config_from_ctor(n_vocab, spec_channels, segment_size, inter_channels, hidde
     elif ms_istft_vits:
         dec = DEC_MS
     elif istft_vits:
-        raise ValueError("istft_vits (single-band iSTFT_Generator) is not built yet "
-                         "(SURVEY §8f rank 1)")
+        dec = DEC_SB
     else:
         raise ValueError("Decoder Error in json file")  # models.py:644 prints this
     cfg = ModelConfig(
@@ -123,7 +130,7 @@ def config_from_ctor(n_vocab, spec_channels, segment_size, inter_channels, hidde
         upsample_initial_channel=int(upsample_initial_channel),
         upsample_kernel_sizes=[int(k) for k in upsample_kernel_sizes],
         gen_istft_n_fft=int(gen_istft_n_fft), gen_istft_hop_size=int(gen_istft_hop_size),
-        subbands=int(subbands) if subbands else 4, n_speakers=int(n_speakers),
+        subbands=1 if dec == DEC_SB else (int(subbands) if subbands else 4), n_speakers=int(n_speakers),
         gin_channels=int(gin_channels), decoder=dec)
     cfg.validate()
     return cfg
@@ -175,8 +182,9 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         ch = C0 >> (i + 1)
         for j, k in enumerate(cfg.resblock_kernel_sizes):
             p = "dec.resblocks.%d." % (i * nk + j)
-            for grp in ("convs1", "convs2"):
-                for m in range(3):
+            groups = (("convs1", 3), ("convs2", 3)) if cfg.resblock == "1" else (("convs", 2),)
+            for grp, n in groups:                      # modules.py:190-206 / 240-244
+                for m in range(n):
                     s[p + "%s.%d.bias" % (grp, m)] = (ch,)
                     s[p + "%s.%d.weight_g" % (grp, m)] = (ch, 1, 1)
                     s[p + "%s.%d.weight_v" % (grp, m)] = (ch, ch, k)
@@ -184,9 +192,10 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
                 s[p + "cond.weight"] = (ch, gin, 1)
                 s[p + "cond.bias"] = (ch,)
     ch = C0 >> len(cfg.upsample_rates)
-    s["dec.subband_conv_post.bias"] = (cfg.post_channels,)
-    s["dec.subband_conv_post.weight_g"] = (cfg.post_channels, 1, 1)
-    s["dec.subband_conv_post.weight_v"] = (cfg.post_channels, ch, 7)
+    post = "dec.conv_post" if cfg.decoder == DEC_SB else "dec.subband_conv_post"   # models.py:272 / 336
+    s[post + ".bias"] = (cfg.post_channels,)
+    s[post + ".weight_g"] = (cfg.post_channels, 1, 1)
+    s[post + ".weight_v"] = (cfg.post_channels, ch, 7)
     if cfg.decoder == DEC_MS:
         s["dec.multistream_conv_post.weight_g"] = (1, 1, 1)
         s["dec.multistream_conv_post.weight_v"] = (1, cfg.subbands, PQMF_TAPS + 1)

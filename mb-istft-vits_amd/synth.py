@@ -32,7 +32,7 @@ def _v_std(name: str, shape, cfg: ModelConfig) -> float:
     """std of a conv weight so that activations stay O(1) through the stack."""
     if name.startswith("dec.ups."):
         cin, _, k = shape
-        stride = 4
+        stride = cfg.upsample_rates[0]
         return float(1.0 / np.sqrt(cin * k / stride))
     if "multistream_conv_post" in name:
         return 0.1
@@ -66,7 +66,7 @@ def make_state_dict(cfg: ModelConfig, seed: int = 1234):
             gname = name[:-1] + "g"
             norm = np.sqrt((v.astype(np.float64) ** 2).reshape(shape[0], -1).sum(1))
             gain = _rs(gname, seed).uniform(0.8, 1.2, size=shape[0])
-            if "subband_conv_post" in name:
+            if "conv_post" in name and "multistream" not in name:
                 gain = gain * 0.5                    # keep exp() of the magnitude head tame
             sd[gname] = (norm * gain).astype(np.float32).reshape(shapes[gname])
         elif name.endswith("emb.weight"):

@@ -235,6 +235,17 @@ def resblock1(W, prefix, x, kernel, dilations, g=None):
     return x
 
 
+def resblock2(W, prefix, x, kernel, dilations, g=None):
+    """modules.py:251-262: x = conv_d(lrelu(x)) + x per dilation."""
+    if g is not None and (prefix + ".cond.weight") in W:
+        x = x + F.conv1d(g, W.w(prefix + ".cond"), W.b(prefix + ".cond"))
+    for m, d in enumerate(dilations):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = conv_same(xt, W.w(prefix + ".convs.%d" % m), W.b(prefix + ".convs.%d" % m), d)
+        x = xt + x
+    return x
+
+
 def decoder_convs(W, cfg, z, g=None, taps=None):
     """z [B,I,T'] -> x_post [B, 72, 16T'+1] (pre-activation output of subband_conv_post)."""
     x = conv_same(z, W.w("dec.conv_pre"), W.b("dec.conv_pre"))
@@ -249,7 +260,8 @@ def decoder_convs(W, cfg, z, g=None, taps=None):
             taps["dec_up_%d" % i] = x
         xs = None
         for j in range(nk):
-            r = resblock1(W, "dec.resblocks.%d" % (i * nk + j), x,
+            rb = resblock1 if str(getattr(cfg, "resblock", "1")) == "1" else resblock2   # models.py:317
+            r = rb(W, "dec.resblocks.%d" % (i * nk + j), x,
                           cfg.resblock_kernel_sizes[j], cfg.resblock_dilation_sizes[j], g)
             xs = r if xs is None else xs + r
         x = xs / nk
@@ -257,7 +269,8 @@ def decoder_convs(W, cfg, z, g=None, taps=None):
             taps["dec_res_%d" % i] = x
     x = F.leaky_relu(x)                                          # slope 0.01 (models.py:363)
     x = torch.cat([x[:, :, 1:2], x], dim=2)                      # ReflectionPad1d((1,0))
-    return conv_same(x, W.w("dec.subband_conv_post"), W.b("dec.subband_conv_post"))
+    post = "dec.conv_post" if "dec.conv_post.bias" in W else "dec.subband_conv_post"   # models.py:272 / 336
+    return conv_same(x, W.w(post), W.b(post))
 
 
 # --------------------------------------------------------------------------
@@ -350,6 +363,11 @@ def waveform_tail(W, cfg, x_post):
     """x_post [B,72,F] -> (o, o_mb, spec, phase), models.py:366-377 / 454-467."""
     B, _, Fr = x_post.shape
     K, nb = cfg.subbands, cfg.gen_istft_n_fft // 2 + 1
+    if K == 1:                                               # iSTFT_Generator (models.py:296-300)
+        spec = torch.exp(x_post[:, :nb])
+        phase = math.pi * torch.sin(x_post[:, nb:])
+        y = istft(spec, phase, cfg.gen_istft_n_fft, cfg.gen_istft_hop_size)
+        return y.unsqueeze(1), None, spec, phase
     x4 = x_post.reshape(B, K, 2 * nb, Fr)
     spec = torch.exp(x4[:, :, :nb])
     phase = math.pi * torch.sin(x4[:, :, nb:])
@@ -400,7 +418,9 @@ def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_s
         o, o_mb, spec, phase = decode(W, cfg, zin, g, taps)
     out = dict(x_enc=x, m_text=m_t, logs_text=logs_t, x_mask=x_mask, logw=logw, w_ceil=w_ceil,
                y_lengths=y_lengths, y_mask=y_mask, attn=attn, m_p=m_p, logs_p=logs_p,
-               z_p=z_p, z=z, o=o, o_mb=o_mb, spec=spec, phase=phase)
+               z_p=z_p, z=z, o=o, spec=spec, phase=phase)
+    if o_mb is not None:
+        out["o_mb"] = o_mb
     if taps:
         out.update(taps)
     return out

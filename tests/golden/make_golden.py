@@ -45,8 +45,10 @@ def import_reference():
     return models, utils, stft, pqmf
 
 
-def build_reference_model(models, utils, cfg_name, n_vocab):
+def build_reference_model(models, utils, cfg_name, n_vocab, overrides=None):
     hps = utils.get_hparams_from_file(os.path.join(REF, "configs", cfg_name + ".json"))
+    for k, v in (overrides or {}).items():          # e.g. resblock "2" (models.py:317), no such config ships
+        hps.model[k] = v
     net = models.SynthesizerTrn(n_vocab, hps.data.filter_length // 2 + 1,
                                 hps.train.segment_size // hps.data.hop_length,
                                 n_speakers=hps.data.n_speakers, **hps.model).eval()
@@ -75,7 +77,8 @@ def capture(net, x, x_lengths, sid):
         hooks.append(net.dec.ups[i].register_forward_hook(grab("dec_up_%d" % i)))
     for j in range(6):
         hooks.append(net.dec.resblocks[j].register_forward_hook(grab("_rb%d" % j)))
-    hooks.append(net.dec.subband_conv_post.register_forward_hook(grab("x_post")))
+    post = net.dec.subband_conv_post if hasattr(net.dec, "subband_conv_post") else net.dec.conv_post
+    hooks.append(post.register_forward_hook(grab("x_post")))
     with torch.no_grad():
         o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer(
             x, x_lengths, sid=sid, noise_scale=0, length_scale=1)
@@ -88,8 +91,10 @@ def capture(net, x, x_lengths, sid):
         taps["dec_res_%d" % i] = xs / 3
     for j in range(6):
         del taps["_rb%d" % j]
-    taps.update(o=o, o_mb=o_mb, spec=spec, phase=phase, attn=attn, y_mask=y_mask, z=z, z_p=z_p,
+    taps.update(o=o, spec=spec, phase=phase, attn=attn, y_mask=y_mask, z=z, z_p=z_p,
                 m_p=m_p, logs_p=logs_p)
+    if o_mb is not None:                            # iSTFT_Generator returns None (models.py:300)
+        taps["o_mb"] = o_mb
     assert sorted(timings) == sorted(["text_encoder", "duration_predictor",
                                       "alignment_and_projection", "flow", "waveform_decoder"])
     return taps
@@ -113,6 +118,10 @@ CASES = [
     ("ms_b2", "ljs_ms_istft_vits", 59, 2, 24, [24, 15], 1234),
     ("uudb_b2", "uudb_ms_istft_vits_ms", 59, 2, 24, [19, 24], 1234),
     ("mb_short", "ljs_mb_istft_vits", 59, 2, 3, [1, 3], 1234),
+    # single-band iSTFT_Generator family and ResBlock2 (row a15)
+    ("sb_mini_b2", "ljs_mini_istft_vits", 59, 2, 12, [12, 7], 1234),
+    ("rb2_mini_b2", "ljs_mini_mb_istft_vits", 59, 2, 16, [16, 11], 1234,
+     {"resblock": "2", "resblock_dilation_sizes": [[1, 3], [1, 3], [1, 3]]}),
 ]
 
 
@@ -123,9 +132,16 @@ def main():
     torch.set_num_threads(4)
     models, utils, stft, pqmf = import_reference()
 
-    for fixture, cfg_name, n_vocab, B, T, lens, wseed in CASES:
-        hps, net = build_reference_model(models, utils, cfg_name, n_vocab)
+    only = set(sys.argv[1:])
+    for case in CASES:
+        fixture, cfg_name, n_vocab, B, T, lens, wseed = case[:7]
+        overrides = case[7] if len(case) > 7 else None
+        if only and fixture not in only:
+            continue
+        hps, net = build_reference_model(models, utils, cfg_name, n_vocab, overrides)
         my_hps = mutils.get_hparams_from_file(mutils.builtin_config(cfg_name))
+        for k, v in (overrides or {}).items():
+            my_hps.model[k] = v
         cfg = mspec.config_from_ctor(n_vocab, my_hps.data.filter_length // 2 + 1,
                                      my_hps.train.segment_size // my_hps.data.hop_length,
                                      n_speakers=my_hps.data.n_speakers, **my_hps.model)
@@ -167,6 +183,8 @@ def main():
             fixture, cfg_name, seed, taps["z"].shape[-1], tuple(taps["o"].shape),
             float(taps["o"].pow(2).mean().sqrt()), margin, size / 1024))
 
+    if only and "signal_ops" not in only:
+        return
     # ---- stand-alone known-answer vectors for the signal ops -------------
     rs = np.random.RandomState(7)
     st = stft.TorchSTFT(filter_length=16, hop_length=4, win_length=16)

@@ -7,8 +7,10 @@ import torch
 from mb_istft_vits_amd import models, synth, utils as mutils, _capi
 
 
-def make_net(cfg_name, n_vocab=59, seed=1234, device="cuda:0"):
+def make_net(cfg_name, n_vocab=59, seed=1234, device="cuda:0", overrides=None):
     hps = mutils.get_hparams_from_file(mutils.builtin_config(cfg_name))
+    for k, v in (overrides or {}).items():
+        hps.model[k] = v
     net = models.SynthesizerTrn(n_vocab, hps.data.filter_length // 2 + 1,
                                 hps.train.segment_size // hps.data.hop_length,
                                 n_speakers=hps.data.n_speakers, **hps.model)

@@ -13,15 +13,21 @@ FIXTURES = {
     "ms_b2": "ljs_ms_istft_vits",
     "uudb_b2": "uudb_ms_istft_vits_ms",
     "mb_short": "ljs_mb_istft_vits",
+    "sb_mini_b2": "ljs_mini_istft_vits",
+    "rb2_mini_b2": "ljs_mini_mb_istft_vits",
 }
+# model-block overrides a fixture was generated with (no reference config ships resblock "2")
+OVERRIDES = {"rb2_mini_b2": {"resblock": "2", "resblock_dilation_sizes": [[1, 3], [1, 3], [1, 3]]}}
 
 
 def load_fixture(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
-def config_for(cfg_name, n_vocab=59):
+def config_for(cfg_name, n_vocab=59, overrides=None):
     hps = mutils.get_hparams_from_file(mutils.builtin_config(cfg_name))
+    for k, v in (overrides or {}).items():
+        hps.model[k] = v
     cfg = mspec.config_from_ctor(n_vocab, hps.data.filter_length // 2 + 1,
                                  hps.train.segment_size // hps.data.hop_length,
                                  n_speakers=hps.data.n_speakers, **hps.model)

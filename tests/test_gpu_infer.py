@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FIXTURES, load_fixture, config_for, thin, rms
+from helpers import FIXTURES, OVERRIDES, load_fixture, config_for, thin, rms
 from oracle import ref_infer as R
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +26,8 @@ def _rel(got, ref):
 def test_infer_matches_reference_golden(fixture):
     from gpu_util import make_net
     gold = load_fixture(fixture)
-    net, sd = make_net(FIXTURES[fixture], int(gold["n_vocab"]), int(gold["weight_seed"]))
+    net, sd = make_net(FIXTURES[fixture], int(gold["n_vocab"]), int(gold["weight_seed"]),
+                       overrides=OVERRIDES.get(fixture))
     x = torch.from_numpy(gold["x"]).cuda()
     xl = torch.from_numpy(gold["x_lengths"]).cuda()
     sid = torch.from_numpy(gold["sid"]).cuda() if "sid" in gold else None
@@ -38,13 +39,18 @@ def test_infer_matches_reference_golden(fixture):
     # durations must be exact (ceil discontinuity)
     assert np.array_equal(attn.sum(2).cpu().numpy(), gold["attn"]), "durations differ"
     assert np.array_equal(y_mask.cpu().numpy(), gold["y_mask"])
+    u = net.cfg.upsample_rates[0]                   # 4 (mb / ms) or 8 (single band)
     shapes = {"x_enc": (B, -1, T), "m_text": (B, -1, T), "logs_text": (B, -1, T), "logw": (B, 1, T),
-              "dec_conv_pre": (B, -1, Tp), "dec_up_0": (B, -1, 4 * Tp), "dec_res_0": (B, -1, 4 * Tp),
-              "dec_up_1": (B, -1, 16 * Tp), "dec_res_1": (B, -1, 16 * Tp), "x_post": (B, 72, 16 * Tp + 1)}
+              "dec_conv_pre": (B, -1, Tp), "dec_up_0": (B, -1, u * Tp), "dec_res_0": (B, -1, u * Tp),
+              "dec_up_1": (B, -1, u * u * Tp), "dec_res_1": (B, -1, u * u * Tp),
+              "x_post": (B, net.cfg.post_channels, u * u * Tp + 1)}
     for name, shp in shapes.items():
         got = thin(name, net.read_stage(name).reshape(*shp).cpu()).numpy()
         report[name] = _rel(got, gold[name])
     outs = dict(m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, spec=spec, phase=phase, o_mb=o_mb, o=o)
+    if "o_mb" not in gold:                          # iSTFT_Generator: (out, None, spec, phase)
+        assert o_mb is None
+        del outs["o_mb"]
     for name, t in outs.items():
         got = thin(name, t.cpu()).numpy()
         assert got.shape == gold[name].shape, (name, got.shape, gold[name].shape)

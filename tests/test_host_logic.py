@@ -35,8 +35,8 @@ def test_header_symbols_all_exported():
 
 
 def test_config_struct_layout_matches_header():
-    # 8 + 1 + 3 + 9 + 4 int32 fields
-    assert C.sizeof(_capi.MbvConfig) == 4 * (9 + 3 + 9 + 4)
+    # 9 scalars + 3 kernel sizes + 9 dilations + resblock_type + 4 trailing scalars, all int32
+    assert C.sizeof(_capi.MbvConfig) == 4 * (9 + 3 + 9 + 1 + 4)
     assert C.sizeof(_capi.MbvOutputs) == 8 * 10
 
 
@@ -55,6 +55,7 @@ def test_create_fails_loudly_without_gpu_or_with_bad_config():
             c.resblock_kernel_sizes[j] = k
             for q, d in enumerate((1, 3, 5)):
                 c.resblock_dilations[j][q] = d
+        c.resblock_type = 1
         assert L.mbv_create(C.byref(c), C.byref(h)) != 0
         assert b"no CPU fallback" in L.mbv_last_error(None)
 
@@ -103,12 +104,15 @@ def test_ctor_rejects_what_is_out_of_scope():
     kw = dict(**hps.model)
     with pytest.raises(ValueError):
         models.SynthesizerTrn(59, 513, 32, **{**kw, "use_sdp": True})
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):                   # single-band family needs its own ups (8, 8)
         models.SynthesizerTrn(59, 513, 32, **{**kw, "mb_istft_vits": False, "istft_vits": True})
     with pytest.raises(ValueError):
         models.SynthesizerTrn(59, 513, 32, **{**kw, "mb_istft_vits": False})   # "Decoder Error"
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):                   # ResBlock2 takes 2 dilations per block
         models.SynthesizerTrn(59, 513, 32, **{**kw, "resblock": "2"})
+    sb = dict(**utils.get_hparams_from_file(utils.builtin_config("ljs_mini_istft_vits")).model)
+    net = models.SynthesizerTrn(59, 513, 32, **sb)
+    assert "dec.conv_post.weight_v" in net.state_dict() and net.cfg.samples_per_frame == 256
 
 
 def test_cpu_model_raises_instead_of_falling_back():
