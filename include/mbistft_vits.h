@@ -161,6 +161,19 @@ int mbv_istft_pqmf(mbv_model *m, const float *x_post, int B, int t_frames, const
                    int multistream, float *o, float *o_mb, float *spec, float *phase,
                    void *stream);
 
+/* ---- spectrogram -> waveform ("istft_finalize") -------------------------------
+ * The last step of the reference's chunked decoding (inferz_test.ipynb cells 6-7,
+ * `istft_finalize`; intent of synthesis_module.py:306-353): chunks of z go through
+ * mbv_decode, the caller cross-fades the returned (spec, phase) along time, and this
+ * entry turns the stitched spectrogram into audio with the MODEL's synthesis bank
+ * (PQMF / trained multistream filter / none for the single-band decoder).
+ *   spec, phase  fp32 [B, 4, 9, F] (single band: [B, 9, F]), phase in radians
+ *   frames       F; must be 16 n + 1 for mb / ms (F - 1 sub-band hops = whole z-frames)
+ *   o            fp32 [B, 1, 16 (F - 1)]  (single band: [B, 1, 4 (F - 1)])
+ *   o_mb         optional, as in mbv_outputs */
+int mbv_istft_finalize(mbv_model *m, const float *spec, const float *phase, int B, int frames,
+                       float *o, float *o_mb, void *stream);
+
 /* ---- introspection (tests, debugging) ---------------------------------------
  * Copies an internal stage tensor of the last call into `dst` (device).
  * Names: "x_enc" [B,H,T], "m_text", "logs_text" [B,I,T], "logw", "w_ceil"

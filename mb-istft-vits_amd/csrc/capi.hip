@@ -1089,6 +1089,33 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   return 0;
 }
 
+int mbv_istft_finalize(mbv_model* m, const float* spec, const float* phase, int B, int frames,
+                       float* o, float* o_mb, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized");
+  if (!spec || !phase || !o || B <= 0 || frames < 2) return m->fail("mbv_istft_finalize: bad arguments");
+  const mbv_config& c = m->cfg;
+  HIPCHK(m, hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  if (c.decoder == MBV_DEC_SINGLEBAND) {
+    IstftSbArgs a{};
+    a.o = o; a.spec = const_cast<float*>(spec); a.phase = const_cast<float*>(phase);
+    a.B = B; a.F = frames; a.exact_math = m->exact_math; a.polar_in = 1;
+    launch_istft_single(a, s);
+  } else {
+    if ((frames - 1) % 16) return m->fail("mbv_istft_finalize: frames must be 16 n + 1 for the 4-band decoders");
+    if ((int64_t)B * 36 * frames * 4 >= (1LL << 31)) return m->fail("mbv_istft_finalize: tensor too large for one launch");
+    IstftArgs a{};
+    a.filt = m->W(m->filt.off); a.o = o; a.o_mb = o_mb;
+    a.spec = const_cast<float*>(spec); a.phase = const_cast<float*>(phase);
+    a.B = B; a.Tp = (frames - 1) / 16; a.multistream = c.decoder == MBV_DEC_MULTISTREAM;
+    a.fixed_bank = !a.multistream; a.exact_math = m->exact_math; a.polar_in = 1;
+    launch_istft_pqmf(a, s);
+  }
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
 int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capacity, void* stream) {
   if (!m || !name) return -1;
   const mbv_config& c = m->cfg;

@@ -114,6 +114,21 @@ __device__ __forceinline__ void polar(float xm, float xp, float& mag, float& ph,
   }
 }
 
+// (magnitude, phase [rad]) given directly: the `istft_finalize` entry of the chunked-decode flow
+template <bool FAST>
+__device__ __forceinline__ void polar_in(float mag, float ph, float& re, float& im, bool need_im) {
+  if constexpr (FAST) {
+    const float t = ph * 0.15915494309189535f;          // radians -> turns
+    re = mag * __builtin_amdgcn_cosf(t);
+    im = need_im ? mag * __builtin_amdgcn_sinf(t) : 0.f;
+  } else {
+    float sn, cs;
+    sincosf(ph, &sn, &cs);
+    re = mag * cs;
+    im = mag * sn;
+  }
+}
+
 // 16-point real inverse DFT of a one-sided spectrum (Im of DC / Nyquist ignored, as c2r
 // does), times hann(16)/16.  Packed real-IFFT: with A_k = X_k + conj(X_{8-k}),
 // D_k = X_k - conj(X_{8-k}), Z_k = A_k + j W^k D_k (W = e^{j 2 pi/16}, k < 8) one has
@@ -166,7 +181,7 @@ __device__ __forceinline__ void irfft16_hann(const float* re, const float* im, f
 
 // `taps` (device, 256 floats, only read by the trainable-bank variant):
 //   t[band][p][i] = 4 h[band][3 - p + 4 i]   (x4 up-sampling gain folded in; 0 where the tap is > 62)
-template <int TM, int NTHREADS, bool FIXED, bool FAST, bool PRE>
+template <int TM, int NTHREADS, bool FIXED, bool FAST, bool PRE, bool POLAR>
 __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) void istft_pqmf_kernel(const IstftArgs a, const float* __restrict__ taps,
                                                               int tiles_per_utt, int total_tiles) {
   constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   // raw buffer descriptors (stride 0, byte range of the whole tensor; launcher checks < 4 GiB)
   constexpr int kRsrcFlags = 0x00020000;
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x_post), 0, a.B * 72 * F * 4, kRsrcFlags);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x_post), 0, POLAR ? 0 : a.B * 72 * F * 4, kRsrcFlags);
   const __amdgpu_buffer_rsrc_t srsrc =
       __builtin_amdgcn_make_buffer_rsrc(a.spec, 0, a.spec ? a.B * 36 * F * 4 : 0, kRsrcFlags);
   const __amdgpu_buffer_rsrc_t prsrc =
@@ -208,23 +223,34 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
     const int f = f_lo + fl;
     float out[16];
     if (f >= 0 && f < F) {
-      // buffer loads: one 32-bit lane offset, the 18 channel strides ride in scalar registers
-      const int voff = ((b * 72 + band * 18) * F + f) * 4;
-      float xin[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k)
-        xin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, k * F * 4, 0));
       float re[9], im[9];
-      // frame f is owned (for the spec/phase outputs) by the tile holding sample 4f
-      const bool own = (4 * f >= m0 && 4 * f < m0 + TM) || (f == F - 1 && m0 + TM >= M);
+      if constexpr (POLAR) {
+        // input = (spec, phase) tensors [B, 4, 9, F] (chunked decode: cross-faded spectrograms)
+        const int so = ((b * 4 + band) * 9 * F + f) * 4;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float mag, ph;
-        polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
-        if (own) {
-          const int so = ((b * 4 + band) * 9 * F + f) * 4;
-          if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
-          if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 0);
+        for (int k = 0; k < 9; ++k) {
+          const float mag = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc, so, k * F * 4, 0));
+          const float ph = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, so, k * F * 4, 0));
+          polar_in<FAST>(mag, ph, re[k], im[k], k != 0 && k != 8);
+        }
+      } else {
+        // buffer loads: one 32-bit lane offset, the 18 channel strides ride in scalar registers
+        const int voff = ((b * 72 + band * 18) * F + f) * 4;
+        float xin[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k)
+          xin[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff, k * F * 4, 0));
+        // frame f is owned (for the spec/phase outputs) by the tile holding sample 4f
+        const bool own = (4 * f >= m0 && 4 * f < m0 + TM) || (f == F - 1 && m0 + TM >= M);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float mag, ph;
+          polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
+          if (own) {
+            const int so = ((b * 4 + band) * 9 * F + f) * 4;
+            if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
+            if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 0);
+          }
         }
       }
       irfft16_hann(re, im, out);
@@ -334,18 +360,28 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
   const int tiles_per_utt = (M + TM - 1) / TM;
   const int total = tiles_per_utt * a.B;
   const dim3 grid(total), block(NT);
-#define MBV_ISTFT_LAUNCH(FIXED, FAST, PRE) \
-  hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, FIXED, FAST, PRE>), grid, block, 0, s, a, a.filt, tiles_per_utt, total)
+#define MBV_ISTFT_LAUNCH(FIXED, FAST, PRE, POLAR) \
+  hipLaunchKernelGGL((istft_pqmf_kernel<TM, NT, FIXED, FAST, PRE, POLAR>), grid, block, 0, s, a, a.filt, tiles_per_utt, total)
+  if (a.polar_in) {          // (spec, phase) input: a.spec / a.phase are read, not written
+    const int v = (a.fixed_bank ? 2 : 0) | (a.exact_math ? 0 : 1);
+    switch (v) {
+      case 0: MBV_ISTFT_LAUNCH(false, false, false, true); break;
+      case 1: MBV_ISTFT_LAUNCH(false, true, false, true); break;
+      case 2: MBV_ISTFT_LAUNCH(true, false, false, true); break;
+      default: MBV_ISTFT_LAUNCH(true, true, false, true); break;
+    }
+    return;
+  }
   const int variant = (a.fixed_bank ? 4 : 0) | (a.exact_math ? 0 : 2) | (a.prescaled ? 1 : 0);
   switch (variant) {
-    case 0: MBV_ISTFT_LAUNCH(false, false, false); break;
-    case 1: MBV_ISTFT_LAUNCH(false, false, true); break;
-    case 2: MBV_ISTFT_LAUNCH(false, true, false); break;
-    case 3: MBV_ISTFT_LAUNCH(false, true, true); break;
-    case 4: MBV_ISTFT_LAUNCH(true, false, false); break;
-    case 5: MBV_ISTFT_LAUNCH(true, false, true); break;
-    case 6: MBV_ISTFT_LAUNCH(true, true, false); break;
-    default: MBV_ISTFT_LAUNCH(true, true, true); break;
+    case 0: MBV_ISTFT_LAUNCH(false, false, false, false); break;
+    case 1: MBV_ISTFT_LAUNCH(false, false, true, false); break;
+    case 2: MBV_ISTFT_LAUNCH(false, true, false, false); break;
+    case 3: MBV_ISTFT_LAUNCH(false, true, true, false); break;
+    case 4: MBV_ISTFT_LAUNCH(true, false, false, false); break;
+    case 5: MBV_ISTFT_LAUNCH(true, false, true, false); break;
+    case 6: MBV_ISTFT_LAUNCH(true, true, false, false); break;
+    default: MBV_ISTFT_LAUNCH(true, true, true, false); break;
   }
 #undef MBV_ISTFT_LAUNCH
 }
@@ -356,7 +392,7 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
 // phase B: one lane per quad of output samples (252 quads): overlap-add of the 4 covering
 // frames, edge-aware envelope, one 16-byte store.
 // ============================================================================
-template <bool FAST, bool PRE>
+template <bool FAST, bool PRE, bool POLAR>
 __global__ __launch_bounds__(256) void istft_single_kernel(const IstftSbArgs a, int tiles_per_utt) {
   constexpr int QPB = 252;                 // output quads per workgroup
   constexpr int NFS = 256;
@@ -371,19 +407,26 @@ __global__ __launch_bounds__(256) void istft_single_kernel(const IstftSbArgs a, 
     const int f = q0 - 1 + tid;
     float out[16];
     if (tid < QPB + 3 && f >= 0 && f < F) {
-      const float* xp = a.x_post + (int64_t)b * 18 * F + f;
-      float xin[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) xin[k] = xp[(int64_t)k * F];
       float re[9], im[9];
-      const bool own = f >= q0 && (f < q0 + QPB || f == F - 1);
+      if constexpr (POLAR) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float mag, ph;
-        polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
-        if (own) {
-          if (a.spec) a.spec[((int64_t)b * 9 + k) * F + f] = mag;
-          if (a.phase) a.phase[((int64_t)b * 9 + k) * F + f] = ph;
+        for (int k = 0; k < 9; ++k)
+          polar_in<FAST>(a.spec[((int64_t)b * 9 + k) * F + f], a.phase[((int64_t)b * 9 + k) * F + f],
+                         re[k], im[k], k != 0 && k != 8);
+      } else {
+        const float* xp = a.x_post + (int64_t)b * 18 * F + f;
+        float xin[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) xin[k] = xp[(int64_t)k * F];
+        const bool own = f >= q0 && (f < q0 + QPB || f == F - 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float mag, ph;
+          polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
+          if (own) {
+            if (a.spec) a.spec[((int64_t)b * 9 + k) * F + f] = mag;
+            if (a.phase) a.phase[((int64_t)b * 9 + k) * F + f] = ph;
+          }
         }
       }
       irfft16_hann(re, im, out);
@@ -417,12 +460,17 @@ __global__ __launch_bounds__(256) void istft_single_kernel(const IstftSbArgs a, 
 void launch_istft_single(const IstftSbArgs& a, hipStream_t s) {
   const int tiles = (a.F - 1 + 251) / 252;
   const dim3 grid(tiles * a.B), block(256);
+  if (a.polar_in) {
+    if (a.exact_math) hipLaunchKernelGGL((istft_single_kernel<false, false, true>), grid, block, 0, s, a, tiles);
+    else hipLaunchKernelGGL((istft_single_kernel<true, false, true>), grid, block, 0, s, a, tiles);
+    return;
+  }
   const int variant = (a.exact_math ? 0 : 2) | (a.prescaled ? 1 : 0);
   switch (variant) {
-    case 0: hipLaunchKernelGGL((istft_single_kernel<false, false>), grid, block, 0, s, a, tiles); break;
-    case 1: hipLaunchKernelGGL((istft_single_kernel<false, true>), grid, block, 0, s, a, tiles); break;
-    case 2: hipLaunchKernelGGL((istft_single_kernel<true, false>), grid, block, 0, s, a, tiles); break;
-    default: hipLaunchKernelGGL((istft_single_kernel<true, true>), grid, block, 0, s, a, tiles); break;
+    case 0: hipLaunchKernelGGL((istft_single_kernel<false, false, false>), grid, block, 0, s, a, tiles); break;
+    case 1: hipLaunchKernelGGL((istft_single_kernel<false, true, false>), grid, block, 0, s, a, tiles); break;
+    case 2: hipLaunchKernelGGL((istft_single_kernel<true, false, false>), grid, block, 0, s, a, tiles); break;
+    default: hipLaunchKernelGGL((istft_single_kernel<true, true, false>), grid, block, 0, s, a, tiles); break;
   }
 }
 

@@ -118,6 +118,7 @@ struct IstftArgs {
   int fixed_bank;        // 1: the PQMF design (cosine-modulated, factorised); 0: arbitrary 4x63 taps
   int exact_math;        // 1: libm expf/sinf/sincosf instead of the hardware transcendentals
   int prescaled;         // 1: x_post rows already carry log2(e) (magnitude) / 1/(2 pi) (phase)
+  int polar_in;          // 1: x_post unused; spec / phase [B,4,9,F] are the INPUT (istft_finalize)
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
 
@@ -129,6 +130,7 @@ struct IstftSbArgs {
   float* phase;          // [B, 9, F] or null
   int B, F;
   int exact_math, prescaled;
+  int polar_in;          // 1: spec / phase [B,9,F] are the input
 };
 void launch_istft_single(const IstftSbArgs& a, hipStream_t s);
 

@@ -357,6 +357,34 @@ class SynthesizerTrn(nn.Module):
         return o, o_mb, spec, phase
 
     @torch.no_grad()
+    def istft_finalize(self, spec, phase):
+        """(spec, phase) -> waveform [B, 1, samples] with the model's synthesis bank: the last step
+        of the reference's chunked decoding (`istft_finalize` in inferz_test.ipynb cell 6; the
+        cross-fade of the chunks' spectrograms stays in the caller).  Accepts the complex
+        spectrogram too (`spec * exp(1j * phase)`), as the notebook passes it."""
+        h = self._ensure_handle()
+        dev = self._device()
+        if phase is None:
+            if not torch.is_complex(spec):
+                raise ValueError("istft_finalize(spec, phase): phase missing and spec is not complex")
+            spec, phase = torch.abs(spec), torch.angle(spec)
+        spec = spec.to(device=dev, dtype=torch.float32).contiguous()
+        phase = phase.to(device=dev, dtype=torch.float32).contiguous()
+        if spec.shape != phase.shape:
+            raise ValueError("spec and phase must have the same shape")
+        sb = self.cfg.decoder == DEC_SB
+        if (spec.dim() != (3 if sb else 4)) or spec.shape[-2] != 9 or (not sb and spec.shape[1] != 4):
+            raise ValueError("spec must be [B, 9, F]" if sb else "spec must be [B, 4, 9, F]")
+        B, Fr = spec.shape[0], spec.shape[-1]
+        n = (4 if sb else 16) * (Fr - 1)
+        o = torch.empty(B, 1, n, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _capi.check(h, _capi.lib().mbv_istft_finalize(h, self._ptr(spec), self._ptr(phase), B, Fr,
+                                                          self._ptr(o), None, self._stream()),
+                        "mbv_istft_finalize")
+        return o
+
+    @torch.no_grad()
     def _speaker_embedding(self, sid):
         h = self._ensure_handle()
         dev = self._device()

@@ -117,3 +117,56 @@ def test_infer_z_only_and_errors():
         net.infer(x[0], xl)
     with pytest.raises(NotImplementedError):
         net(x, xl, None, None)
+
+
+@pytest.mark.parametrize("cfg_name", ["ljs_mb_istft_vits", "ljs_ms_istft_vits", "ljs_mini_istft_vits"])
+def test_chunked_decode_with_istft_finalize(cfg_name):
+    """The notebooks' streaming flow (inferz_test.ipynb cells 6-7): infer_z_only -> .dec on
+    overlapping z-chunks -> cross-fade (spec, phase) as complex spectrograms -> istft_finalize.
+    Checked against the oracle doing the same stitching on the CPU."""
+    from gpu_util import make_net
+    net, sd = make_net(cfg_name)
+    rs = np.random.RandomState(4)
+    Tz, chunk, hop = 23, 10, 6
+    z = torch.from_numpy(rs.standard_normal((2, 192, Tz)).astype(np.float32))
+    sb = cfg_name.endswith("mini_istft_vits")
+    fpz = 64 if sb else 16                     # spectrogram frames per z-frame
+
+    def stitch(dec):
+        full = None
+        for i0 in range(0, Tz, hop):
+            zc = z[:, :, i0:min(i0 + chunk, Tz)]
+            spec, phase = dec(zc)
+            comp = spec * torch.exp(1j * phase)
+            if full is None:
+                full = comp
+            else:
+                want = (i0 + zc.shape[-1]) * fpz + 1
+                ov = full.shape[-1] + comp.shape[-1] - want          # frames both chunks cover
+                alpha = torch.linspace(0.0, 1.0, ov).view(*([1] * (comp.dim() - 1)), ov)
+                merged = full[..., -ov:] * (1 - alpha) + comp[..., :ov] * alpha
+                full = torch.cat([full[..., :-ov], merged, comp[..., ov:]], dim=-1)
+            if i0 + chunk >= Tz:
+                break
+        return full
+
+    _, cfg = config_for(cfg_name)
+    W = R.Weights(sd)
+    with torch.no_grad():
+        ref_full = stitch(lambda zc: R.decode(W, cfg, zc)[2:4])
+        ref_spec, ref_phase = torch.abs(ref_full), torch.angle(ref_full)
+        if sb:
+            ref_o = R.istft(ref_spec, ref_phase).unsqueeze(1)
+        else:
+            B = ref_spec.shape[0]
+            y = R.istft(ref_spec.reshape(B * 4, 9, -1), ref_phase.reshape(B * 4, 9, -1)).reshape(B, 4, -1)
+            h = W.w("dec.multistream_conv_post")[0] if "dec.multistream_conv_post.weight_v" in W \
+                else torch.from_numpy(R.pqmf_synthesis_filter())
+            ref_o = R.synthesis_filter_apply(R.zero_stuff(y), h)
+    gpu_full = stitch(lambda zc: tuple(t.cpu() for t in net.dec(zc.cuda())[2:4]))
+    assert gpu_full.shape == ref_full.shape and gpu_full.shape[-1] == Tz * fpz + 1
+    o = net.istft_finalize(gpu_full.cuda(), None)                      # complex input, as the notebook
+    o2 = net.istft_finalize(torch.abs(gpu_full).cuda(), torch.angle(gpu_full).cuda())
+    assert torch.equal(o, o2)
+    assert o.shape == ref_o.shape
+    assert rms(o.cpu().numpy() - ref_o.numpy()) < 1e-4
