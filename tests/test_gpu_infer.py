@@ -167,6 +167,6 @@ def test_chunked_decode_with_istft_finalize(cfg_name):
     assert gpu_full.shape == ref_full.shape and gpu_full.shape[-1] == Tz * fpz + 1
     o = net.istft_finalize(gpu_full.cuda(), None)                      # complex input, as the notebook
     o2 = net.istft_finalize(torch.abs(gpu_full).cuda(), torch.angle(gpu_full).cuda())
-    assert torch.equal(o, o2)
+    assert float((o - o2).abs().max()) < 1e-5       # abs/angle taken on the GPU vs on the CPU
     assert o.shape == ref_o.shape
     assert rms(o.cpu().numpy() - ref_o.numpy()) < 1e-4
