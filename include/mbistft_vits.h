@@ -174,6 +174,17 @@ int mbv_istft_pqmf(mbv_model *m, const float *x_post, int B, int t_frames, const
 int mbv_istft_finalize(mbv_model *m, const float *spec, const float *phase, int B, int frames,
                        float *o, float *o_mb, void *stream);
 
+/* ---- wire-format epilogue -----------------------------------------------------
+ * replaces the NumPy post-processing of the service wrapper (tts_vits.py:204-217):
+ * per-utterance peak normalisation to 0.9 (if auto_normalize and peak > 0.01), clip to
+ * [-1, 1], * 32767, truncation to int16.  Bit-exact with the reference's fp32 NumPy.
+ *   wave        fp32 [B, 1, stride] device
+ *   y_lengths   int64 [B] device frames per utterance (valid samples = 256 * y_lengths),
+ *               or NULL = every row is `stride` valid samples
+ *   pcm         int16 [B, stride] device; samples past the valid length are 0 */
+int mbv_pcm16(mbv_model *m, const float *wave, const int64_t *y_lengths, int B, int64_t stride,
+              int auto_normalize, int16_t *pcm, void *stream);
+
 /* ---- introspection (tests, debugging) ---------------------------------------
  * Copies an internal stage tensor of the last call into `dst` (device).
  * Names: "x_enc" [B,H,T], "m_text", "logs_text" [B,I,T], "logw", "w_ceil"

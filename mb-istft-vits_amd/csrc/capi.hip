@@ -76,6 +76,7 @@ struct mbv_model {
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
+  unsigned* peak_buf = nullptr; int peak_cap = 0;   // per-utterance peaks of mbv_pcm16
   bool user_tab_is_pqmf = false;
   int xpost_F = 1;             // frames per row of the last x_post stage tensor
   int xpost_rows = 72;         // 72 (4 bands x 18) or 18 (single band)
@@ -785,6 +786,7 @@ void mbv_destroy(mbv_model* m) {
   if (m->scrA) (void)hipFree(m->scrA);
   if (m->scrB) (void)hipFree(m->scrB);
   if (m->user_tab) (void)hipFree(m->user_tab);
+  if (m->peak_buf) (void)hipFree(m->peak_buf);
   if (m->ev_ok) { for (auto& e : m->ev) (void)hipEventDestroy(e); for (auto& e : m->evk) (void)hipEventDestroy(e); }
   delete m;
 }
@@ -1112,6 +1114,22 @@ int mbv_istft_finalize(mbv_model* m, const float* spec, const float* phase, int 
     a.fixed_bank = !a.multistream; a.exact_math = m->exact_math; a.polar_in = 1;
     launch_istft_pqmf(a, s);
   }
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
+int mbv_pcm16(mbv_model* m, const float* wave, const int64_t* y_lengths, int B, int64_t stride,
+              int auto_normalize, int16_t* pcm, void* stream) {
+  if (!m) return 1;
+  if (!wave || !pcm || B <= 0 || stride <= 0) return m->fail("mbv_pcm16: bad arguments");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  if (m->peak_cap < B) {
+    if (m->peak_buf) HIPCHK(m, hipFree(m->peak_buf));
+    HIPCHK(m, hipMalloc((void**)&m->peak_buf, (size_t)B * sizeof(unsigned)));
+    m->peak_cap = B;
+  }
+  launch_pcm16(wave, y_lengths, B, stride, 256, auto_normalize, m->peak_buf, reinterpret_cast<short*>(pcm),
+               (hipStream_t)stream);
   HIPCHK(m, hipGetLastError());
   return 0;
 }

@@ -137,6 +137,10 @@ void launch_istft_single(const IstftSbArgs& a, hipStream_t s);
 // x_post rows back to the reference's units (stage introspection): inverse of the pre-scaling
 void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, hipStream_t s);
 
+// float waveform -> int16 PCM (normalise / clip / scale), tts_vits.py:204-217
+void launch_pcm16(const float* x, const int64_t* lens, int B, int64_t stride, int spf, int auto_normalize,
+                  unsigned* peak_scratch, short* out, hipStream_t s);
+
 // misc
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
 

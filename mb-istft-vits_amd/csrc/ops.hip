@@ -280,6 +280,55 @@ void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, 
   hipLaunchKernelGGL(unscale_xpost_kernel, dim3(blocks), dim3(256), 0, s, src, dst, rows, F, n);
 }
 
+// ---------------------------------------------------------------------------
+// Wire-format epilogue of the service wrapper (tts_vits.py:204-217): per utterance
+//   peak = max |x| over the valid samples; if auto_normalize and peak > 0.01: x = x / peak * 0.9
+//   x = clip(x, -1, 1); pcm = int16(x * 32767)   (truncation toward zero, as ndarray.astype)
+// Same fp32 operation order as the NumPy code, so the int16 stream is bit-exact.
+// ---------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* x, const int64_t* lens, int64_t stride, int spf,
+                              unsigned* peak_bits) {
+  const int b = blockIdx.y;
+  const int64_t n = lens ? lens[b] * spf : stride;
+  const float* xb = x + (int64_t)b * stride;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(xb[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(&peak_bits[b], __float_as_uint(m));   // m >= 0: bit order == value order
+}
+
+__global__ void pcm16_kernel(const float* x, const int64_t* lens, int64_t stride, int spf,
+                             const unsigned* peak_bits, int auto_normalize, short* out) {
+  const int b = blockIdx.y;
+  const int64_t n = lens ? lens[b] * spf : stride;
+  const float peak = __uint_as_float(peak_bits[b]);
+  const bool norm = auto_normalize && peak > 0.01f;
+  const float* xb = x + (int64_t)b * stride;
+  short* ob = out + (int64_t)b * stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < n) {
+      v = xb[i];
+      if (norm) v = (v / peak) * 0.9f;
+      v = fminf(fmaxf(v, -1.f), 1.f);
+      v = v * 32767.f;
+    }
+    ob[i] = (short)(int)v;
+  }
+}
+
+void launch_pcm16(const float* x, const int64_t* lens, int B, int64_t stride, int spf, int auto_normalize,
+                  unsigned* peak_scratch, short* out, hipStream_t s) {
+  (void)hipMemsetAsync(peak_scratch, 0, (size_t)B * sizeof(unsigned), s);
+  int bx = (int)((stride + 255) / 256);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3(bx, B), dim3(256), 0, s, x, lens, stride, spf, peak_scratch);
+  hipLaunchKernelGGL(pcm16_kernel, dim3(bx, B), dim3(256), 0, s, x, lens, stride, spf, peak_scratch,
+                     auto_normalize, out);
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -385,6 +385,24 @@ class SynthesizerTrn(nn.Module):
         return o
 
     @torch.no_grad()
+    def to_pcm16(self, wave, y_lengths=None, auto_normalize=True):
+        """Waveform [B, 1, n] -> int16 PCM [B, n] on the GPU: the normalise / clip / *32767 /
+        astype(int16) sequence of the service wrapper (tts_vits.py:204-217), per utterance over
+        its valid 256 * y_lengths samples (rest zero).  Bit-exact with the NumPy code."""
+        h = self._ensure_handle()
+        dev = self._device()
+        wave = wave.to(device=dev, dtype=torch.float32).contiguous()
+        B, n = wave.shape[0], wave.shape[-1]
+        if y_lengths is not None:
+            y_lengths = y_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        pcm = torch.empty(B, n, device=dev, dtype=torch.int16)
+        with torch.cuda.device(dev):
+            _capi.check(h, _capi.lib().mbv_pcm16(h, self._ptr(wave), self._ptr(y_lengths), B, n,
+                                                 int(bool(auto_normalize)), self._ptr(pcm), self._stream()),
+                        "mbv_pcm16")
+        return pcm
+
+    @torch.no_grad()
     def _speaker_embedding(self, sid):
         h = self._ensure_handle()
         dev = self._device()

@@ -424,3 +424,15 @@ def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_s
     if taps:
         out.update(taps)
     return out
+
+
+# --------------------------------------------------------------------------
+# wire-format epilogue of the service wrapper (tts_vits.py:204-217), NumPy as there
+# --------------------------------------------------------------------------
+def to_pcm16(audio, auto_normalize=True):
+    """audio: 1-D float32 -> int16 (normalise to 0.9 peak if peak > 0.01, clip, * 32767, truncate)."""
+    audio = np.asarray(audio, np.float32)
+    peak = np.abs(audio).max() if audio.size else 0.0
+    if auto_normalize and peak > 0.01:
+        audio = (audio / peak) * 0.9
+    return (np.clip(audio, -1.0, 1.0) * 32767).astype(np.int16)

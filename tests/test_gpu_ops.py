@@ -135,3 +135,24 @@ def test_istft_fast_vs_exact_transcendentals():
     print("istft rms err vs oracle: exact %.2e fast %.2e (signal rms %.2f)" % (e_exact, e_fast, rms(o_ref)))
     assert e_exact < 2e-5 * max(1.0, rms(o_ref))
     assert e_fast < 2e-5 * max(1.0, rms(o_ref))
+
+
+def test_pcm16_epilogue_bit_exact(net):
+    """float -> int16 wire format (tts_vits.py:204-217): bit-exact against the NumPy restatement,
+    per utterance over its valid samples; quiet utterances (peak <= 0.01) are not normalised."""
+    rs = np.random.RandomState(2)
+    B, frames = 5, 9
+    n = 256 * frames
+    wave = (rs.standard_normal((B, 1, n)) * 0.4).astype(np.float32)
+    wave[1] *= 5.0                 # clips without normalisation
+    wave[2] *= 0.01                # peak below the 0.01 threshold -> left alone
+    ylen = np.array([9, 4, 9, 1, 7], np.int64)
+    for auto in (True, False):
+        pcm = net.to_pcm16(torch.from_numpy(wave).cuda(), torch.from_numpy(ylen).cuda(), auto_normalize=auto).cpu().numpy()
+        assert pcm.dtype == np.int16 and pcm.shape == (B, n)
+        for b in range(B):
+            v = 256 * ylen[b]
+            assert np.array_equal(pcm[b, :v], R.to_pcm16(wave[b, 0, :v], auto)), (auto, b)
+            assert not pcm[b, v:].any()
+    full = net.to_pcm16(torch.from_numpy(wave).cuda()).cpu().numpy()
+    assert np.array_equal(full[0], R.to_pcm16(wave[0, 0]))
