@@ -84,6 +84,9 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
   const int wrow0 = m0 + wm * 32 * WM;
   int nact = (a.M - wrow0 + 31) / 32;
   nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
+  // ... and of its 32-column tiles that start inside the sequence (ragged last block)
+  int nj = (a.T - (t0 + wn * 32 * WN) + 31) / 32;
+  nj = nj < 0 ? 0 : (nj > WN ? WN : nj);
 
   const float* xb = a.x + (int64_t)b * a.x_bstride;
   const int len_in = a.in_lens ? a.in_lens[b] : 0x7fffffff;
@@ -228,7 +231,8 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
         _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                           \
           _Pragma("unroll") for (int i = 0; i < WM; ++i)                           \
             _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
+              if (j < nj)                                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
         if constexpr (WN < 4) {
           // operands double-buffered one step ahead (4 accumulators: short steps)
           MBV_LOAD_AB(0, a0, b0);

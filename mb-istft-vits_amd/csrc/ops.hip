@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const float* m_t, const flo
     }
     j = cb[lo] > tp ? lo : -1;               // -1: all-zero durations (y_len clamped to 1)
   }
-  if (y_mask) y_mask[(int64_t)b * Tp + tp] = tp < yl ? 1.f : 0.f;
-  for (int c = 0; c < C; ++c) {
+  if (y_mask && blockIdx.z == 0) y_mask[(int64_t)b * Tp + tp] = tp < yl ? 1.f : 0.f;
+  const int c_lo = blockIdx.z * 16, c_hi = c_lo + 16 < C ? c_lo + 16 : C;   // 16 channels per block
+  for (int c = c_lo; c < c_hi; ++c) {
     const int64_t o = ((int64_t)b * C + c) * Tp + tp;
     float m = 0.f, lg = 0.f;
     if (j >= 0) {
@@ -217,7 +218,7 @@ void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, c
                    const int* ylen, const float* noise, float noise_scale, float* m_p,
                    float* logs_p, float* z_p, float* z, float* attn, float* y_mask, int B, int C,
                    int T, int Tp, hipStream_t s) {
-  dim3 grid((Tp + 255) / 256, B);
+  dim3 grid((Tp + 255) / 256, B, (C + 15) / 16);
   hipLaunchKernelGGL(expand_kernel, grid, dim3(256), 0, s, m_t, logs_t, src_bstride, cum, ylen, noise,
                      noise_scale, m_p, logs_p, z_p, z, y_mask, C, T, Tp);
   if (attn) {
