@@ -26,6 +26,7 @@
 // Frames / samples in the halos are recomputed, not exchanged; consecutive
 // tiles are mapped to the same XCD so halo rows hit in its L2.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mbv {
 
@@ -354,8 +355,8 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   }
 }
 
-void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
-  constexpr int TM = 480, NT = 512;
+template <int TM, int NT>
+static void launch_istft_pqmf_t(const IstftArgs& a, hipStream_t s) {
   const int M = 64 * a.Tp;
   const int tiles_per_utt = (M + TM - 1) / TM;
   const int total = tiles_per_utt * a.B;
@@ -384,6 +385,14 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
     default: MBV_ISTFT_LAUNCH(true, true, true, false); break;
   }
 #undef MBV_ISTFT_LAUNCH
+}
+
+void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
+  // 480 sub-band samples x 512 threads (4 workgroups / CU) by default; MBV_ISTFT_TILE=224 selects
+  // the 224 x 256-thread shape (8 workgroups / CU) for A/B runs
+  static const int tile = [] { const char* e = getenv("MBV_ISTFT_TILE"); return e ? atoi(e) : 480; }();
+  if (tile == 224) launch_istft_pqmf_t<224, 256>(a, s);
+  else launch_istft_pqmf_t<480, 512>(a, s);
 }
 
 // ============================================================================
