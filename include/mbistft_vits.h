@@ -106,7 +106,9 @@ int mbv_missing_weights(mbv_model *m, char *buf, size_t cap);
  *   ids      int64 [B, T]   device     token ids
  *   lengths  int64 [B]      device     valid tokens per utterance
  *   sid      int64 [B]      device     speaker ids, NULL iff n_speakers == 0
- *   y_lengths_out int64 [B] device     frames per utterance (clamped >= 1)
+ *   y_lengths_out int64 [B] device     frames per utterance (clamped >= 1); -1 marks an utterance
+ *                                      with a token id, length or speaker id out of range (the
+ *                                      reference's nn.Embedding raises IndexError there)
  * The caller reads max(y_lengths) back (the one host sync of the path,
  * mirroring commons.py:123) and passes it to mbv_synthesize. */
 int mbv_encode(mbv_model *m, const int64_t *ids, const int64_t *lengths, const int64_t *sid,

@@ -835,7 +835,7 @@ int mbv_speaker_embedding(mbv_model* m, const int64_t* sid, int B, float* out, v
   if (!m->finalized) return m->fail("weights not finalized");
   if (!m->emb_g.present) return m->fail("model has no speaker embedding (n_speakers <= 1)");
   HIPCHK(m, hipSetDevice(m->cfg.device));
-  launch_gather_rows(m->W(m->emb_g.off), sid, out, B, m->cfg.gin_channels, m->cfg.n_speakers,
+  launch_gather_rows(m->W(m->emb_g.off), sid, out, B, m->cfg.gin_channels, m->cfg.n_speakers, nullptr,
                      (hipStream_t)stream);
   HIPCHK(m, hipGetLastError());
   return 0;
@@ -853,7 +853,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   hipStream_t s = (hipStream_t)stream;
   const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels, gin = c.gin_channels;
   const size_t BT = (size_t)B * T;
-  size_t need = (BT * (H * 5 + 3 * H + Fc + 2 * I + 2 * kDpFilter + 4) + (size_t)B * (gin + H + 8)) * 4 + 64 * 256;
+  size_t need = (BT * (H * 5 + 3 * H + Fc + 2 * I + 2 * kDpFilter + 4) + (size_t)B * (gin + H + 12)) * 4 + 64 * 256;
   if (ensure(m, &m->scrA, &m->scrA_bytes, need)) return 1;
   Bump sc{m->scrA, m->scrA_bytes};
   float* x = sc.take<float>(BT * H);
@@ -870,12 +870,13 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   m->cum = sc.take<int>(BT);
   m->lens32 = sc.take<int>(B);
   m->ylen32 = sc.take<int>(B);
+  int* bad = sc.take<int>(B);
   m->gvec = sc.take<float>((size_t)B * (gin ? gin : 1));
   float* dpc = sc.take<float>((size_t)B * H);
   m->stages.clear();
 
   HIPCHK(m, hipEventRecord(m->ev[0], s));
-  launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, B, T, H, c.n_vocab, s);
+  launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, bad, B, T, H, c.n_vocab, s);
   const int64_t bsH = (int64_t)H * T;
   for (int i = 0; i < c.n_layers; ++i) {
     const auto& L = m->enc[i];
@@ -910,7 +911,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   m->has_g = c.n_speakers > 0;
   const float* cadd = nullptr;
   if (m->has_g) {
-    launch_gather_rows(m->W(m->emb_g.off), sid, m->gvec, B, gin, c.n_speakers, s);
+    launch_gather_rows(m->W(m->emb_g.off), sid, m->gvec, B, gin, c.n_speakers, bad, s);
     if (m->dp_cw.present) {
       launch_cond_gemv(m->gvec, nullptr, nullptr, m->W(m->dp_cw.off), m->W(m->dp_cb.off), dpc, B, gin, H, s);
       cadd = dpc;
@@ -929,7 +930,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   }
   launch_layernorm(h1, nullptr, m->W(m->dp_g2.off), m->W(m->dp_b2.off), h2, B, kDpFilter, T, 1, nullptr, s);
   launch_durations(h2, m->W(m->dp_pw.off), m->W(m->dp_pb.off), m->lens32, length_scale, m->logw,
-                   m->w_ceil, m->cum, m->ylen32, y_lengths_out, B, kDpFilter, T, s);
+                   m->w_ceil, m->cum, m->ylen32, y_lengths_out, bad, B, kDpFilter, T, s);
   HIPCHK(m, hipEventRecord(m->ev[2], s));
   HIPCHK(m, hipGetLastError());
   m->B = B; m->T = T; m->encoded = true; m->ev_a = true; m->ev_b = false;

@@ -77,8 +77,9 @@ struct ConvTArgs {
 void launch_convt(const ConvTArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- text encoder pieces
+// bad[b] is set when an utterance has a token id / length outside the valid range
 void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
-                  int B, int T, int H, int n_vocab, hipStream_t s);
+                  int* bad, int B, int T, int H, int n_vocab, hipStream_t s);
 // y = LN_c( a (+ r) [relu] ) * gamma + beta  [* mask]
 void launch_layernorm(const float* a, const float* r, const float* gamma, const float* beta,
                       float* y, int B, int C, int T, int pre_relu, const int* out_lens,
@@ -92,7 +93,7 @@ void launch_rel_attention(const float* qkv, const float* emb_k, const float* emb
 // logw = (w . h*mask + b) * mask ; w_ceil = ceil(exp(logw)*mask*scale) ; cum = cumsum ; ylen
 void launch_durations(const float* h, const float* w, const float* b, const int* lens,
                       float length_scale, float* logw, float* w_ceil, int* cum, int* ylen32,
-                      int64_t* ylen64, int B, int C, int T, hipStream_t s);
+                      int64_t* ylen64, const int* bad, int B, int C, int T, hipStream_t s);
 // m_t / logs_t: [B, C, T] views with batch stride src_bstride (halves of the enc_p.proj output)
 void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, const int* cum,
                    const int* ylen, const float* noise, float noise_scale, float* m_p,
@@ -104,7 +105,7 @@ void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, c
 void launch_cond_gemv(const float* g, const float* table, const int64_t* sid, const float* W,
                       const float* bias, float* out, int B, int Cin, int Cout, hipStream_t s);
 void launch_gather_rows(const float* table, const int64_t* sid, float* out, int B, int C,
-                        int n_rows, hipStream_t s);
+                        int n_rows, int* bad, hipStream_t s);
 
 // ---------------------------------------------------------------- fused iSTFT + PQMF
 struct IstftArgs {

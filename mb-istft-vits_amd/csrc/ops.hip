@@ -9,23 +9,31 @@ namespace mbv {
 // Also narrows the int64 lengths to the int32 copy the other kernels use.
 // ---------------------------------------------------------------------------
 __global__ void embed_kernel(const int64_t* ids, const int64_t* lens, const float* emb, float* x,
-                             int* lens32, int B, int T, int H, int n_vocab, float scale) {
+                             int* lens32, int* bad, int B, int T, int H, int n_vocab, float scale) {
   const int b = blockIdx.z;
   const int c = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0 && c == 0) lens32[b] = (int)lens[b];
+  if (t == 0 && c == 0) {
+    const long long l = lens[b];
+    lens32[b] = l < 0 ? 0 : (l > T ? T : (int)l);
+    if (l < 0 || l > T) bad[b] = 1;               // x_lengths outside [0, T]
+  }
   if (t >= T) return;
   const int len = (int)lens[b];
   long long id = ids[(int64_t)b * T + t];
-  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);
+  if (id < 0 || id >= n_vocab) {                    // nn.Embedding would raise IndexError: report it
+    if (c == 0) bad[b] = 1;                         // (mbv_encode returns y_lengths = -1 for the utterance)
+    id = 0;
+  }
   float v = emb[id * H + c] * scale;
   x[((int64_t)b * H + c) * T + t] = t < len ? v : 0.f;
 }
 
 void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
-                  int B, int T, int H, int n_vocab, hipStream_t s) {
+                  int* bad, int B, int T, int H, int n_vocab, hipStream_t s) {
+  (void)hipMemsetAsync(bad, 0, (size_t)B * sizeof(int), s);
   dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(embed_kernel, grid, dim3(64), 0, s, ids, lens, emb, x, lens32, B, T, H, n_vocab,
+  hipLaunchKernelGGL(embed_kernel, grid, dim3(64), 0, s, ids, lens, emb, x, lens32, bad, B, T, H, n_vocab,
                      sqrtf((float)H));
 }
 
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* h, const fl
                                                         const float* bias, const int* lens,
                                                         float length_scale, float* logw,
                                                         float* w_ceil, int* cum, int* ylen32,
-                                                        int64_t* ylen64, int C, int T) {
+                                                        int64_t* ylen64, const int* bad, int C, int T) {
   __shared__ int scan[256];
   __shared__ int carry_s;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -148,15 +156,15 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* h, const fl
   if (tid == 0) {
     const int total = carry_s < 1 ? 1 : carry_s;
     ylen32[b] = total;
-    if (ylen64) ylen64[b] = total;
+    if (ylen64) ylen64[b] = (bad && bad[b]) ? -1 : total;     // -1: invalid token id / length / sid
   }
 }
 
 void launch_durations(const float* h, const float* w, const float* b, const int* lens,
                       float length_scale, float* logw, float* w_ceil, int* cum, int* ylen32,
-                      int64_t* ylen64, int B, int C, int T, hipStream_t s) {
+                      int64_t* ylen64, const int* bad, int B, int C, int T, hipStream_t s) {
   hipLaunchKernelGGL(durations_kernel, dim3(B), dim3(256), 0, s, h, w, b, lens, length_scale, logw,
-                     w_ceil, cum, ylen32, ylen64, C, T);
+                     w_ceil, cum, ylen32, ylen64, bad, C, T);
 }
 
 // ---------------------------------------------------------------------------
@@ -250,19 +258,22 @@ void launch_cond_gemv(const float* g, const float* table, const int64_t* sid, co
 }
 
 __global__ void gather_rows_kernel(const float* table, const int64_t* sid, float* out, int C,
-                                   int n_rows) {
+                                   int n_rows, int* bad) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   long long r = sid[b];
-  r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+  if (r < 0 || r >= n_rows) {
+    if (bad && c == 0) bad[b] = 1;
+    r = 0;
+  }
   out[(int64_t)b * C + c] = table[r * C + c];
 }
 
 void launch_gather_rows(const float* table, const int64_t* sid, float* out, int B, int C,
-                        int n_rows, hipStream_t s) {
+                        int n_rows, int* bad, hipStream_t s) {
   dim3 grid((C + 127) / 128, B);
-  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(128), 0, s, table, sid, out, C, n_rows);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(128), 0, s, table, sid, out, C, n_rows, bad);
 }
 
 __global__ void unscale_xpost_kernel(const float* src, float* dst, int rows, int F, int64_t n) {

@@ -271,7 +271,11 @@ class SynthesizerTrn(nn.Module):
             _capi.check(h, L.mbv_encode(h, self._ptr(x), self._ptr(x_lengths), self._ptr(sid), B, T,
                                         float(length_scale), self._ptr(y_lengths), stream),
                         "mbv_encode")
-            Tp = int(y_lengths.max().item())        # the one host sync (commons.py:123)
+            lo, hi = torch.aminmax(y_lengths)
+            Tp = int(hi.item())                     # the one host sync (commons.py:123)
+            if int(lo.item()) < 0:                  # flagged by the kernels, no extra sync
+                raise IndexError("index out of range in self (token id, x_lengths or sid outside the "
+                                 "model's tables)")
             if frames_hook is not None:             # sharded run: pad to the global T' max
                 Tp = int(frames_hook(Tp))
             # the reference draws randn_like(m_p) even at noise_scale == 0 (models.py:729)

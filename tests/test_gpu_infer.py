@@ -117,6 +117,14 @@ def test_infer_z_only_and_errors():
         net.infer(x[0], xl)
     with pytest.raises(NotImplementedError):
         net(x, xl, None, None)
+    bad = x.clone()
+    bad[1, 2] = 59                                  # == n_vocab: nn.Embedding raises IndexError
+    with pytest.raises(IndexError):
+        net.infer(bad, xl, noise_scale=0)
+    with pytest.raises(IndexError):
+        net.infer(x, torch.tensor([9, 10]).cuda(), noise_scale=0)      # x_lengths > T
+    again = net.infer(x, xl, noise_scale=0)          # the handle is still usable afterwards
+    assert torch.equal(again[0], full[0])
 
 
 @pytest.mark.parametrize("cfg_name", ["ljs_mb_istft_vits", "ljs_ms_istft_vits", "ljs_mini_istft_vits"])
