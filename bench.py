@@ -143,7 +143,7 @@ def main():
     # ---- roofline of the fused iSTFT+PQMF launch, waveform-only mode ----
     roof, roof_conv = None, None
     if rank == 0:
-        from tests_support import istft_waveform_only_ms
+        from mb_istft_vits_amd.benchutil import istft_waveform_only_ms
         wave_ms = istft_waveform_only_ms(net, B, Tp, iters=50)
         frames = B * Tp
         ach = ISTFT_BYTES_PER_FRAME * frames / (wave_ms * 1e-3) / 1e9

@@ -1,9 +1,9 @@
-"""Small measurement helper shared by bench.py and the profiling scripts."""
+"""Measurement helper shared by bench.py and scripts/prof_kernels.py (not on the product path)."""
 import ctypes as C
 
 import torch
 
-from mb_istft_vits_amd import _capi
+from . import _capi
 
 
 def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True):

@@ -19,7 +19,7 @@ B = int(os.environ.get("PROF_B", "64"))
 Tp = int(os.environ.get("PROF_TP", "566"))
 
 from gpu_util import make_net, op_conv1d     # noqa: E402
-from tests_support import istft_waveform_only_ms   # noqa: E402
+from mb_istft_vits_amd.benchutil import istft_waveform_only_ms   # noqa: E402
 
 net = make_net("ljs_mini_mb_istft_vits")[0]
 if which in ("istft", "both"):
