@@ -20,7 +20,7 @@
 //      so cos(theta_k(j)) = (-1)^(j/8) cos(theta_k(j mod 8))) -> LDS Us[q][.]
 //      Trainable bank (MS): the band samples go to LDS ys[band][.] as they are.
 //   C  one lane per sub-band sample m: the 4 polyphase outputs o[4m..4m+3];
-//      fixed bank: 16 prototype taps each (64 FMA per lane instead of 252),
+//      fixed bank: 16 prototype taps each (63 FMA per lane instead of 252),
 //      trainable bank: <= 16 taps x 4 bands each.  The zero-stuffed x4
 //      upsampling never materialises; one 16-byte store per lane.
 // Frames / samples in the halos are recomputed, not exchanged; consecutive
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   constexpr int NF = TM / 4 + 7;          // frames a tile touches per band
   constexpr int NFS = ((NF + 31) / 32) * 32 + 8;   // LDS frame stride, == 8 (mod 32): conflict-free phase B
   constexpr int YL = TM + 16;             // sub-band samples incl. PQMF halo
-  constexpr int NROW = FIXED ? 8 : 4;     // rows of the phase-B product (U_q or y_band)
+  constexpr int NROW = 4;                 // rows of the phase-B product (U_1..U_4 or y_band)
   static_assert(4 * NF <= NTHREADS, "one lane per (band, frame)");
   static_assert(YL <= NTHREADS, "one lane per sub-band time index");
   static_assert(NROW * YL <= 4 * 16 * NFS, "phase-B product aliases the frame buffer");
@@ -306,10 +306,13 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
       }
     }
     if constexpr (FIXED) {
+      // Of the 8 modulation phases only 4 are distinct: U_0 = U_1, U_5 = -U_4, U_6 = -U_3,
+      // U_7 = -U_2 (theta_k(q) is symmetric about q = 0.5 and anti-symmetric about q = 4.5).
+      // Row r holds U_{r+1}; the signs are folded into the tap constants of phase C.
 #pragma unroll
-      for (int qq = 0; qq < 8; ++qq)
-        rowv[qq] = PQMF_C[qq] * y[0] + PQMF_C[8 + qq] * y[1] + PQMF_C[16 + qq] * y[2] +
-                   PQMF_C[24 + qq] * y[3];
+      for (int r = 0; r < 4; ++r)
+        rowv[r] = PQMF_C[r + 1] * y[0] + PQMF_C[8 + r + 1] * y[1] + PQMF_C[16 + r + 1] * y[2] +
+                  PQMF_C[24 + r + 1] * y[3];
     } else {
 #pragma unroll
       for (int band = 0; band < 4; ++band) rowv[band] = y[band];
@@ -333,7 +336,11 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int j = 3 - p + 4 * i;           // tap index; y index m - 7 + i
-            if (j <= 62) acc[p] = fmaf(PQMF_G[j], prod[(j & 7) * YL + tid + 1 + i], acc[p]);
+            if (j <= 62) {
+              constexpr int ROW[8] = {0, 0, 1, 2, 3, 3, 2, 1};          // U_q -> stored row
+              constexpr float SGN[8] = {1.f, 1.f, 1.f, 1.f, 1.f, -1.f, -1.f, -1.f};
+              acc[p] = fmaf(PQMF_G[j] * SGN[j & 7], prod[ROW[j & 7] * YL + tid + 1 + i], acc[p]);
+            }
           }
         }
       } else {
