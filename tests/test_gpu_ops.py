@@ -156,3 +156,52 @@ def test_pcm16_epilogue_bit_exact(net):
             assert not pcm[b, v:].any()
     full = net.to_pcm16(torch.from_numpy(wave).cuda()).cpu().numpy()
     assert np.array_equal(full[0], R.to_pcm16(wave[0, 0]))
+
+
+def test_c_abi_error_paths(net):
+    """Misuse of the C ABI returns an error code + message (no crash, no exception across the ABI)."""
+    import ctypes as C
+    from mb_istft_vits_amd import _capi
+    L = _capi.lib()
+    c = _capi.MbvConfig()
+    c.struct_bytes = C.sizeof(_capi.MbvConfig)
+    c.n_vocab, c.inter_channels, c.hidden_channels, c.filter_channels = 59, 192, 96, 768
+    c.n_heads, c.n_layers, c.kernel_size, c.upsample_initial_channel = 2, 3, 3, 256
+    for j, k in enumerate((3, 7, 11)):
+        c.resblock_kernel_sizes[j] = k
+        for q, d in enumerate((1, 3, 5)):
+            c.resblock_dilations[j][q] = d
+    c.resblock_type, c.decoder, c.device = 1, 0, 0
+    h = C.c_void_p()
+    assert L.mbv_create(C.byref(c), C.byref(h)) == 0
+    try:
+        # phase B without phase A / without weights
+        out = _capi.MbvOutputs()
+        assert L.mbv_synthesize(h, 10, None, 0.0, 0, C.byref(out), None) != 0
+        assert b"mbv_encode" in L.mbv_last_error(h)
+        ids = torch.zeros(1, 4, dtype=torch.int64, device="cuda")
+        lens = torch.tensor([4], device="cuda")
+        yl = torch.zeros(1, dtype=torch.int64, device="cuda")
+        assert L.mbv_encode(h, C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), None, 1, 4,
+                            C.c_float(1.0), C.c_void_p(yl.data_ptr()), None) != 0
+        assert b"finalize" in L.mbv_last_error(h)
+        assert L.mbv_finalize_weights(h, None) != 0 and b"missing weight" in L.mbv_last_error(h)
+        n_missing = L.mbv_missing_weights(h, None, 0)
+        assert n_missing > 100
+        # wrong shape and training-only key
+        w = np.zeros((59, 95), np.float32)
+        shp = (C.c_int64 * 2)(59, 95)
+        assert L.mbv_load_weight(h, b"enc_p.emb.weight", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
+        assert b"shape mismatch" in L.mbv_last_error(h)
+        assert L.mbv_load_weight(h, b"enc_q.pre.weight", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
+        assert b"not a weight of the infer path" in L.mbv_last_error(h)
+        shp = (C.c_int64 * 2)(59, 96)
+        w = np.zeros((59, 96), np.float32)
+        assert L.mbv_load_weight(h, b"enc_p.emb.weight", w.ctypes.data_as(C.c_void_p), shp, 2) == 0
+        assert L.mbv_missing_weights(h, None, 0) == n_missing - 1
+    finally:
+        L.mbv_destroy(h)
+    with pytest.raises(ValueError):
+        net.istft_finalize(torch.zeros(1, 4, 9, 18, device="cuda"), torch.zeros(1, 4, 9, 17, device="cuda"))
+    with pytest.raises(_capi.MbvError, match="16 n \\+ 1"):
+        net.istft_finalize(torch.zeros(1, 4, 9, 18, device="cuda"), torch.zeros(1, 4, 9, 18, device="cuda"))
