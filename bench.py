@@ -47,7 +47,7 @@ def decoder_flops_per_frame(cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--t-text", type=int, default=200)
@@ -171,20 +171,37 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_infer
         nb = 8
-        torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
         W = ref_infer.Weights(sd_np)
-        ref_infer.infer(W, cfg, x_np[:2], xl_np[:2], sid_np[:2] if sid_np is not None else None)
-        ts = []
-        for _ in range(2):
-            t1 = time.perf_counter()
-            r = ref_infer.infer(W, cfg, x_np[:nb], xl_np[:nb], sid_np[:nb] if sid_np is not None else None)
-            ts.append(time.perf_counter() - t1)
-        cpu_samples = int(r["y_lengths"].sum()) * cfg.samples_per_frame
-        cpu = {"value": round(cpu_samples / min(ts), 1), "unit": "samples/s",
-               "cores": torch.get_num_threads(), "kind": "port",
-               "sample": "first %d utterances of the batch-%d workload, 1 warm-up (B=2) + best of 2 "
-                         "timed oracle infer calls" % (nb, B),
-               "rtf": round(min(ts) / (cpu_samples / sr), 5)}
+        sid8 = sid_np[:nb] if sid_np is not None else None
+
+        def cpu_run(threads):
+            torch.set_num_threads(threads)
+            ref_infer.infer(W, cfg, x_np[:2], xl_np[:2], sid8[:2] if sid8 is not None else None)   # warm-up
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                r = ref_infer.infer(W, cfg, x_np[:nb], xl_np[:nb], sid8)
+                ts.append(time.perf_counter() - t1)
+            ts.sort()
+            return ts[1], int(r["y_lengths"].sum()) * cfg.samples_per_frame        # median of 3
+
+        n_all = max(1, min(os.cpu_count() or 1, 64))
+        t_all, cpu_samples = cpu_run(n_all)
+        t_8, _ = cpu_run(min(8, n_all))
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        cpu = {"value": round(cpu_samples / t_all, 1), "unit": "samples/s", "cores": n_all, "kind": "port",
+               "sample": "first %d utterances of the batch-%d workload; oracle (PyTorch-CPU fp32 restatement "
+                         "of the reference) infer, 1 warm-up (B=2) + median of 3 timed calls" % (nb, B),
+               "rtf": round(t_all / (cpu_samples / sr), 5),
+               "value_8_threads": round(cpu_samples / t_8, 1), "cpu_model": cpu_model,
+               "torch": torch.__version__}
 
     if rank == 0:
         line = {
