@@ -203,3 +203,31 @@ def test_shape_sweep_against_oracle(B, T, ragged):
     assert _rel(z.cpu().numpy(), ref["z"].numpy()) < 5e-5
     assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
     assert np.array_equal(attn.cpu().numpy(), ref["attn"].numpy())
+
+
+def test_full_size_batch64_properties():
+    """BASELINE.json configs[1] at full size (ljs_mb, B=64, T_text=200): size-independent checks.
+      * determinism: two runs are bitwise identical;
+      * batch independence: a sub-batch run padded to the same T' reproduces its rows bitwise
+        (no cross-utterance arithmetic anywhere on the path);
+      * spot parity: the oracle on two utterances at the same padded T' (the decoder is unmasked,
+        so the pad length matters) agrees within the 1e-4 RMS bar."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits")
+    x, xl, _ = synth.synthetic_batch(net.cfg, 64, 200, seed=0)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), _), ylen = net.infer_with_lengths(
+        xg, xlg, noise_scale=0, length_scale=1)
+    Tp = z.shape[-1]
+    assert o.shape == (64, 1, 256 * Tp) and int(ylen.max()) == Tp
+    assert torch.isfinite(o).all()
+    o2 = net.infer(xg, xlg, noise_scale=0, length_scale=1)[0]
+    assert torch.equal(o, o2)
+    r = net._run(xg[40:48], xlg[40:48], None, 0, 1, None, True, frames_hook=lambda t: Tp)
+    assert torch.equal(r[0], o[40:48]) and torch.equal(r[6][0], z[40:48])
+    torch.set_num_threads(8)
+    ref = R.infer(sd, net.cfg, x[[3, 57]], xl[[3, 57]], t_frames=Tp)
+    got = o[[3, 57]].cpu().numpy()
+    assert np.array_equal(ylen[[3, 57]].cpu().numpy(), ref["y_lengths"].numpy())
+    assert rms(got - ref["o"].numpy()) < 1e-4
