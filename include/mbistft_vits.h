@@ -52,6 +52,7 @@ typedef struct mbv_config {
   int32_t n_layers;                  /* 6 (mini: 3) */
   int32_t kernel_size;               /* FFN kernel, 3 */
   int32_t upsample_initial_channel;  /* 512 (mini: 256) */
+  int32_t spec_channels;             /* filter_length / 2 + 1 = 513: input of enc_q (voice conversion) */
   int32_t resblock_kernel_sizes[3];  /* 3,7,11 */
   int32_t resblock_dilations[3][3];  /* 1,3,5 each (ResBlock2: first two used) */
   int32_t resblock_type;             /* 1 = ResBlock1 (modules.py:187), 2 = ResBlock2 (modules.py:237) */
@@ -162,6 +163,20 @@ int mbv_kernel_times_ms(mbv_model *m, float out[2]);
 int mbv_istft_pqmf(mbv_model *m, const float *x_post, int B, int t_frames, const float *filter,
                    int multistream, float *o, float *o_mb, float *spec, float *phase,
                    void *stream);
+
+/* ---- voice conversion -------------------------------------------------------------
+ * replaces SynthesizerTrn.voice_conversion (models.py:790-798): posterior encoder on the source
+ * spectrogram, forward flow with the source speaker, reverse flow + decoder with the target.
+ *   y          fp32 [B, spec_channels, T] linear spectrogram     y_lengths int64 [B]
+ *   sid_src, sid_tgt  int64 [B]
+ *   noise      fp32 [B, 192, T] standard-normal draws of PosteriorEncoder (models.py:245), or
+ *              NULL for the deterministic z = m_q
+ *   outs       o, o_mb, spec, phase as in mbv_decode (T' = T); y_mask [B,1,T];
+ *              z -> z (posterior sample), z_p -> z_p (source-normalised), m_p -> z_hat
+ *   status     int32 [B] device, optional: non-zero where y_lengths / sid were out of range */
+int mbv_voice_conversion(mbv_model *m, const float *y, const int64_t *y_lengths,
+                         const int64_t *sid_src, const int64_t *sid_tgt, int B, int T,
+                         const float *noise, const mbv_outputs *outs, int32_t *status, void *stream);
 
 /* ---- spectrogram -> waveform ("istft_finalize") -------------------------------
  * The last step of the reference's chunked decoding (inferz_test.ipynb cells 6-7,

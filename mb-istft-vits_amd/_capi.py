@@ -16,7 +16,7 @@ SYMBOLS = [
     "mbv_abi_version", "mbv_create", "mbv_destroy", "mbv_last_error", "mbv_load_weight",
     "mbv_finalize_weights", "mbv_missing_weights", "mbv_encode", "mbv_synthesize", "mbv_decode",
     "mbv_speaker_embedding", "mbv_stage_times_ms", "mbv_istft_pqmf", "mbv_read_stage",
-    "mbv_op_conv1d", "mbv_kernel_times_ms", "mbv_istft_finalize", "mbv_pcm16",
+    "mbv_op_conv1d", "mbv_kernel_times_ms", "mbv_istft_finalize", "mbv_pcm16", "mbv_voice_conversion",
 ]
 
 
@@ -25,7 +25,7 @@ class MbvConfig(C.Structure):
         ("struct_bytes", C.c_int32), ("n_vocab", C.c_int32), ("inter_channels", C.c_int32),
         ("hidden_channels", C.c_int32), ("filter_channels", C.c_int32), ("n_heads", C.c_int32),
         ("n_layers", C.c_int32), ("kernel_size", C.c_int32),
-        ("upsample_initial_channel", C.c_int32),
+        ("upsample_initial_channel", C.c_int32), ("spec_channels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilations", (C.c_int32 * 3) * 3),
         ("resblock_type", C.c_int32),
         ("n_speakers", C.c_int32), ("gin_channels", C.c_int32), ("decoder", C.c_int32),
@@ -81,6 +81,7 @@ def lib():
     L.mbv_kernel_times_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.mbv_istft_pqmf.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp]
     L.mbv_istft_finalize.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.mbv_voice_conversion.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MbvOutputs), vp, vp]
     L.mbv_pcm16.argtypes = [vp, vp, vp, i32, C.c_int64, i32, vp, vp]
     L.mbv_read_stage.argtypes = [vp, C.c_char_p, vp, C.c_int64, vp]
     L.mbv_read_stage.restype = C.c_int64

@@ -67,6 +67,8 @@ struct mbv_model {
   struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers]; PVec cw, cb; };
   Flow flow[kNFlows];
   PConv conv_pre, conv_post;
+  static constexpr int kEncQLayers = 16;     // models.py:646
+  struct EncQ { PConv pre, proj, in[kEncQLayers], rs[kEncQLayers]; PVec cw, cb; int cin_pad = 0; } encq;
   struct Up { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, Mpad = 0; } ups[2];
   struct RB { PConv c1[3], c2[3]; PVec cw, cb; } rb[6];
   PVec emb_g;
@@ -185,6 +187,29 @@ void build_expected(mbv_model* m) {
     add_key(m, "dec.multistream_conv_post.weight_g", {1, 1, 1});
     add_key(m, "dec.multistream_conv_post.weight_v", {1, 4, 63});
   }
+  // enc_q (PosteriorEncoder, models.py:217-246): only voice_conversion reads it, but it is part of
+  // every reference checkpoint, so the keys are accepted and required like the rest
+  add_key(m, "enc_q.pre.weight", {H, c.spec_channels, 1});
+  add_key(m, "enc_q.pre.bias", {H});
+  for (int l = 0; l < mbv_model::kEncQLayers; ++l) {
+    const int rs = l < mbv_model::kEncQLayers - 1 ? 2 * H : H;
+    char q[64];
+    snprintf(q, sizeof q, "enc_q.enc.in_layers.%d.", l);
+    add_key(m, std::string(q) + "bias", {2 * H});
+    add_key(m, std::string(q) + "weight_g", {2 * H, 1, 1});
+    add_key(m, std::string(q) + "weight_v", {2 * H, H, 5});
+    snprintf(q, sizeof q, "enc_q.enc.res_skip_layers.%d.", l);
+    add_key(m, std::string(q) + "bias", {rs});
+    add_key(m, std::string(q) + "weight_g", {rs, 1, 1});
+    add_key(m, std::string(q) + "weight_v", {rs, H, 1});
+  }
+  if (gin) {
+    add_key(m, "enc_q.enc.cond_layer.bias", {2 * H * mbv_model::kEncQLayers});
+    add_key(m, "enc_q.enc.cond_layer.weight_g", {2 * H * mbv_model::kEncQLayers, 1, 1});
+    add_key(m, "enc_q.enc.cond_layer.weight_v", {2 * H * mbv_model::kEncQLayers, gin, 1});
+  }
+  add_key(m, "enc_q.proj.weight", {2 * I, H, 1});
+  add_key(m, "enc_q.proj.bias", {2 * I});
   for (int f = 0; f < kNFlows; ++f) {
     snprintf(p, sizeof p, "flow.flows.%d.", 2 * f);
     const std::string s(p);
@@ -311,6 +336,18 @@ struct Packer {
     return conv(w, Cout, Cin, K, rows, {}, b, nullptr);
   }
 };
+
+// WN in_layer (modules.py:130-135): gated packing, 32-row tiles alternate tanh half / sigmoid half
+PConv pack_gated(Packer& P, const std::string& prefix, int H, int K) {
+  const std::vector<float> w = P.dense(prefix);
+  std::vector<int> rows(2 * H), brows(2 * H);
+  for (int ch = 0; ch < H; ++ch) {
+    rows[(ch / 32) * 64 + (ch % 32)] = ch;
+    rows[(ch / 32) * 64 + 32 + (ch % 32)] = H + ch;
+  }
+  for (int r = 0; r < 2 * H; ++r) brows[r] = r;        // bias stays in reference order
+  return P.conv(w, 2 * H, H, K, rows, {}, &P.t(prefix + ".bias").data, &brows);
+}
 
 // modified Bessel I0 (power series; converges fast for x <= 9)
 double bessel_i0(double x) {
@@ -441,16 +478,7 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
     for (int l = 0; l < kFlowLayers; ++l) {
       char q[64];
       snprintf(q, sizeof q, "enc.in_layers.%d", l);
-      {   // gated packing: 32-row tiles alternate tanh half / sigmoid half
-        const std::vector<float> w = P.dense(s + q);
-        std::vector<int> rows(2 * H), brows(2 * H);
-        for (int ch = 0; ch < H; ++ch) {
-          rows[(ch / 32) * 64 + (ch % 32)] = ch;
-          rows[(ch / 32) * 64 + 32 + (ch % 32)] = H + ch;
-        }
-        for (int r = 0; r < 2 * H; ++r) brows[r] = r;      // bias stays in reference order
-        F.in[l] = P.conv(w, 2 * H, H, kFlowK, rows, {}, &P.t(s + q + ".bias").data, &brows);
-      }
+      F.in[l] = pack_gated(P, s + q, H, kFlowK);
       snprintf(q, sizeof q, "enc.res_skip_layers.%d", l);
       F.rs[l] = P.conv_plain(s + q);
     }
@@ -464,6 +492,32 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       for (int r = 0; r < half; ++r) rows[r] = flipped ? half - 1 - r : r;
       F.post = P.conv(w, half, H, 1, rows, {}, &P.t(s + "post.bias").data, nullptr);
     }
+  }
+
+  // ---- posterior encoder (voice conversion only)
+  {
+    auto& Q = m->encq;
+    const int cin = c.spec_channels, cpad = (int)align_up(cin, 32);
+    Q.cin_pad = cpad;
+    const std::vector<float>& w0 = P.t("enc_q.pre.weight").data;       // [H][cin][1]
+    std::vector<float> w((size_t)H * cpad, 0.f);
+    for (int co = 0; co < H; ++co)
+      std::memcpy(&w[(size_t)co * cpad], &w0[(size_t)co * cin], (size_t)cin * sizeof(float));
+    std::vector<int> rows(H);
+    for (int r = 0; r < H; ++r) rows[r] = r;
+    Q.pre = P.conv(w, H, cpad, 1, rows, {}, &P.t("enc_q.pre.bias").data, nullptr);
+    for (int l = 0; l < mbv_model::kEncQLayers; ++l) {
+      char q[64];
+      snprintf(q, sizeof q, "enc_q.enc.in_layers.%d", l);
+      Q.in[l] = pack_gated(P, q, H, 5);
+      snprintf(q, sizeof q, "enc_q.enc.res_skip_layers.%d", l);
+      Q.rs[l] = P.conv_plain(q);
+    }
+    if (gin) {
+      Q.cw = P.vec_data(P.dense("enc_q.enc.cond_layer"));
+      Q.cb = P.vec("enc_q.enc.cond_layer.bias");
+    }
+    Q.proj = P.conv_plain("enc_q.proj");
   }
 
   // ---- decoder
@@ -708,6 +762,61 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   }
   HIPCHK(m, hipEventRecord(m->evk[2], s));
   m->evk_set = true;
+  return 0;
+}
+
+
+// WN stack (modules.py:148-176): h (in place) -> skip; `nl` layers, gate conditioning from gvec
+int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, int nl, const PVec& cw, const PVec& cb,
+           const float* gvec, float* hbuf, float* acts, float* skip, float* gc, const int* lens, int B,
+           int T, hipStream_t s) {
+  const mbv_config& c = m->cfg;
+  const int H = c.hidden_channels, gin = c.gin_channels;
+  const int64_t bsH = (int64_t)H * T;
+  const bool cond = gvec && gin && cw.present;
+  if (cond) launch_cond_gemv(gvec, nullptr, nullptr, m->W(cw.off), m->W(cb.off), gc, B, gin, 2 * H * nl, s);
+  for (int l = 0; l < nl; ++l) {
+    {
+      ConvArgs a = conv_args(m, in_l[l], hbuf, bsH, T, acts, bsH, T, B);
+      a.epi = EPI_GATE; a.gate_half = H;
+      if (cond) { a.gate_cond = gc + (size_t)l * 2 * H; a.gate_cond_bstride = 2 * H * nl; }
+      launch_conv1d(a, s);
+    }
+    {
+      ConvArgs a = conv_args(m, rs_l[l], acts, bsH, T, hbuf, bsH, T, B);
+      a.epi = EPI_RES_SKIP; a.out_lens = lens; a.skip = skip;
+      a.split = l < nl - 1 ? H : 0;
+      a.skip_accum = l > 0;
+      launch_conv1d(a, s);
+    }
+  }
+  return 0;
+}
+
+// One ResidualCouplingLayer (modules.py:334-353) in place on z [B, I, T]; the channel Flip that
+// precedes (reverse) / follows (forward) it is folded into the packing, see do_finalize.
+//   reverse: x1 = (x1 - m) * mask          forward: x1 = m + x1 * mask = (x1 + m) * mask
+int run_coupling(mbv_model* m, int f, bool reverse, float* z, const float* gvec, float* hbuf, float* acts,
+                 float* skip, float* gc, const int* lens, int B, int T, hipStream_t s) {
+  const mbv_config& c = m->cfg;
+  const int H = c.hidden_channels, I = c.inter_channels, half = I / 2;
+  const int64_t bsI = (int64_t)I * T, bsH = (int64_t)H * T;
+  const auto& F = m->flow[f];
+  const bool flipped = (f % 2) == 1;
+  float* x0 = flipped ? z + (size_t)half * T : z;
+  float* x1 = flipped ? z : z + (size_t)half * T;
+  {
+    ConvArgs a = conv_args(m, F.pre, x0, bsI, T, hbuf, bsH, T, B);
+    a.out_lens = lens;
+    launch_conv1d(a, s);
+  }
+  run_wn(m, F.in, F.rs, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, lens, B, T, s);
+  {
+    ConvArgs a = conv_args(m, F.post, skip, bsH, T, x1, bsI, T, B);
+    a.in_lens = lens; a.epi = EPI_COUPLE; a.out_lens = lens;
+    a.couple_sign = reverse ? -1.f : 1.f;
+    launch_conv1d(a, s);
+  }
   return 0;
 }
 
@@ -965,6 +1074,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   float* acts = sc.take<float>(BTp * H);
   float* skip = sc.take<float>(BTp * H);
   float* gc = sc.take<float>((size_t)B * 2 * H * kFlowLayers);
+  (void)gin;
 
   HIPCHK(m, hipEventRecord(m->ev[3], s));
   // m_text / logs_text are the two halves of enc_p.proj's output [B, 2I, T]
@@ -975,43 +1085,8 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   HIPCHK(m, hipEventRecord(m->ev[4], s));
 
   // ---- reverse flows, in place on z (models.py:207-214, modules.py:334-353)
-  const int half = I / 2;
-  const int64_t bsI = (int64_t)I * Tp, bsH = (int64_t)H * Tp;
-  for (int f = kNFlows - 1; f >= 0; --f) {
-    const auto& F = m->flow[f];
-    const bool flipped = (f % 2) == 1;
-    float* x0 = flipped ? z + (size_t)half * Tp : z;
-    float* x1 = flipped ? z : z + (size_t)half * Tp;
-    {
-      ConvArgs a = conv_args(m, F.pre, x0, bsI, Tp, hbuf, bsH, Tp, B);
-      a.out_lens = m->ylen32;
-      launch_conv1d(a, s);
-    }
-    const bool cond = m->has_g && gin && F.cw.present;
-    if (cond)
-      launch_cond_gemv(m->gvec, nullptr, nullptr, m->W(F.cw.off), m->W(F.cb.off), gc, B, gin,
-                       2 * H * kFlowLayers, s);
-    for (int l = 0; l < kFlowLayers; ++l) {
-      {
-        ConvArgs a = conv_args(m, F.in[l], hbuf, bsH, Tp, acts, bsH, Tp, B);
-        a.epi = EPI_GATE; a.gate_half = H;
-        if (cond) { a.gate_cond = gc + (size_t)l * 2 * H; a.gate_cond_bstride = 2 * H * kFlowLayers; }
-        launch_conv1d(a, s);
-      }
-      {
-        ConvArgs a = conv_args(m, F.rs[l], acts, bsH, Tp, hbuf, bsH, Tp, B);
-        a.epi = EPI_RES_SKIP; a.out_lens = m->ylen32; a.skip = skip;
-        a.split = l < kFlowLayers - 1 ? H : 0;
-        a.skip_accum = l > 0;
-        launch_conv1d(a, s);
-      }
-    }
-    {
-      ConvArgs a = conv_args(m, F.post, skip, bsH, Tp, x1, bsI, Tp, B);
-      a.in_lens = m->ylen32; a.epi = EPI_COUPLE; a.out_lens = m->ylen32;
-      launch_conv1d(a, s);
-    }
-  }
+  for (int f = kNFlows - 1; f >= 0; --f)
+    run_coupling(m, f, true, z, m->has_g ? m->gvec : nullptr, hbuf, acts, skip, gc, m->ylen32, B, Tp, s);
   HIPCHK(m, hipEventRecord(m->ev[5], s));
   if (run_dec) {
     if (run_decoder(m, z, Tp, m->ylen32, m->has_g ? m->gvec : nullptr, B, Td, outs, s, sc)) return 1;
@@ -1088,6 +1163,73 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   a.B = B; a.Tp = t_frames; a.multistream = multistream & 1;
   a.fixed_bank = filter == nullptr; a.exact_math = m->exact_math; a.prescaled = (multistream >> 1) & 1;
   launch_istft_pqmf(a, s);
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
+int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths, const int64_t* sid_src,
+                         const int64_t* sid_tgt, int B, int T, const float* noise, const mbv_outputs* outs,
+                         int32_t* status, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized");
+  const mbv_config& c = m->cfg;
+  if (c.n_speakers <= 0 || !m->emb_g.present)
+    return m->fail("n_speakers have to be larger than 0.");              // models.py:791 assert
+  if (!y || !y_lengths || !sid_src || !sid_tgt || !outs || B <= 0 || T <= 0)
+    return m->fail("mbv_voice_conversion: bad arguments");
+  HIPCHK(m, hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int H = c.hidden_channels, I = c.inter_channels, gin = c.gin_channels, SC = c.spec_channels;
+  const auto& Q = m->encq;
+  const size_t BT = (size_t)B * T;
+  size_t need = (BT * ((size_t)Q.cin_pad + 3 * H + 4 * I) + (size_t)B * (2 * gin + 2 * H * mbv_model::kEncQLayers + 16)) * 4 +
+                64 * 256 + decoder_scratch_bytes(c, B, T);
+  if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
+  Bump sc{m->scrB, m->scrB_bytes};
+  m->stages.clear();
+  float* ypad = sc.take<float>(BT * Q.cin_pad);
+  float* hbuf = sc.take<float>(BT * H);
+  float* acts = sc.take<float>(BT * H);
+  float* skip = sc.take<float>(BT * H);
+  float* stats = sc.take<float>(BT * 2 * I);
+  float* zbuf = outs->z ? outs->z : sc.take<float>(BT * I);
+  float* zhat = outs->m_p ? outs->m_p : sc.take<float>(BT * I);
+  float* g_src = sc.take<float>((size_t)B * gin);
+  float* g_tgt = sc.take<float>((size_t)B * gin);
+  float* gc = sc.take<float>((size_t)B * 2 * H * mbv_model::kEncQLayers);
+  int* lens = sc.take<int>(B);
+  int* bad = sc.take<int>(B);
+
+  launch_lens_to_i32(y_lengths, lens, B, T, bad, s);
+  launch_gather_rows(m->W(m->emb_g.off), sid_src, g_src, B, gin, c.n_speakers, bad, s);
+  launch_gather_rows(m->W(m->emb_g.off), sid_tgt, g_tgt, B, gin, c.n_speakers, bad, s);
+  if (status) HIPCHK(m, hipMemcpyAsync(status, bad, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  // the 1x1 `pre` conv reads channel groups of 32: zero-pad spec_channels (513) to a multiple of 32
+  launch_fill(ypad, 0.f, (int64_t)BT * Q.cin_pad, s);
+  HIPCHK(m, hipMemcpy2DAsync(ypad, (size_t)Q.cin_pad * T * 4, y, (size_t)SC * T * 4, (size_t)SC * T * 4, B,
+                             hipMemcpyDeviceToDevice, s));
+  const int64_t bsH = (int64_t)H * T;
+  {   // enc_q (models.py:239-246): pre * mask -> WN(g_src) -> proj * mask -> sample
+    ConvArgs a = conv_args(m, Q.pre, ypad, (int64_t)Q.cin_pad * T, T, hbuf, bsH, T, B);
+    a.out_lens = lens;
+    launch_conv1d(a, s);
+  }
+  run_wn(m, Q.in, Q.rs, mbv_model::kEncQLayers, Q.cw, Q.cb, g_src, hbuf, acts, skip, gc, lens, B, T, s);
+  {
+    ConvArgs a = conv_args(m, Q.proj, skip, bsH, T, stats, (int64_t)2 * I * T, T, B);
+    a.in_lens = lens; a.out_lens = lens;
+    launch_conv1d(a, s);
+  }
+  launch_posterior_sample(stats, noise, lens, zbuf, B, I, T, s);
+  // forward flow with the source speaker (models.py:795), then reverse with the target (:796)
+  HIPCHK(m, hipMemcpyAsync(zhat, zbuf, BT * I * 4, hipMemcpyDeviceToDevice, s));
+  for (int f = 0; f < kNFlows; ++f)
+    run_coupling(m, f, false, zhat, g_src, hbuf, acts, skip, gc, lens, B, T, s);
+  if (outs->z_p) HIPCHK(m, hipMemcpyAsync(outs->z_p, zhat, BT * I * 4, hipMemcpyDeviceToDevice, s));
+  for (int f = kNFlows - 1; f >= 0; --f)
+    run_coupling(m, f, true, zhat, g_tgt, hbuf, acts, skip, gc, lens, B, T, s);
+  if (outs->y_mask) launch_sequence_mask(lens, outs->y_mask, B, T, s);
+  if (run_decoder(m, zhat, T, lens, g_tgt, B, T, outs, s, sc)) return 1;
   HIPCHK(m, hipGetLastError());
   return 0;
 }

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
           } break;
           case EPI_COUPLE: {
             const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
-            a.y[o] = (a.y[o] - v * mask) * mask;
+            a.y[o] = (a.y[o] + a.couple_sign * v * mask) * mask;
           } break;
           default: break;
         }

@@ -15,7 +15,7 @@ enum ConvEpilogue : int {
   EPI_RESID_ACC = 2, // y = ((accum_in ? accum_in : 0) + acc + bias + res (+chan_add)) * out_scale
   EPI_GATE = 3,      // rows come in (tanh-tile, sigmoid-tile) pairs: y[c] = tanh(.)*sigmoid(.)
   EPI_RES_SKIP = 4,  // row < split: xio = (xio + v) * mask ; else skip[row-split] (+)= v
-  EPI_COUPLE = 5,    // y = (y - (acc + bias) * mask) * mask
+  EPI_COUPLE = 5,    // y = (y + couple_sign * (acc + bias) * mask) * mask   (sign -1: reverse flow)
 };
 
 struct ConvArgs {
@@ -56,6 +56,7 @@ struct ConvArgs {
   float* skip;             // RES_SKIP: [B, M - split, T]
   int split;               // RES_SKIP
   int skip_accum;          // RES_SKIP: skip += v instead of skip = v
+  float couple_sign;       // COUPLE: -1 reverse (x1 - m), +1 forward (x1 + m)
   int B;
   int debug;               // timing experiments only (MBV_CONV_DEBUG): 1 = no restaging, 3 = no MFMA
 };
@@ -141,6 +142,12 @@ void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, 
 // float waveform -> int16 PCM (normalise / clip / scale), tts_vits.py:204-217
 void launch_pcm16(const float* x, const int64_t* lens, int B, int64_t stride, int spf, int auto_normalize,
                   unsigned* peak_scratch, short* out, hipStream_t s);
+
+// z = (m + noise * exp(logs)) * mask   (PosteriorEncoder, models.py:245); stats = [B, 2I, T]
+void launch_posterior_sample(const float* stats, const float* noise, const int* lens, float* z, int B,
+                             int I, int T, hipStream_t s);
+void launch_sequence_mask(const int* lens, float* mask, int B, int T, hipStream_t s);   // commons.py:121
+void launch_lens_to_i32(const int64_t* lens, int* out, int B, int T, int* bad, hipStream_t s);
 
 // misc
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);

@@ -341,6 +341,46 @@ void launch_pcm16(const float* x, const int64_t* lens, int B, int64_t stride, in
                      auto_normalize, out);
 }
 
+__global__ void posterior_sample_kernel(const float* stats, const float* noise, const int* lens,
+                                        float* z, int I, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float m = stats[((int64_t)b * 2 * I + c) * T + t];
+  const float lg = stats[((int64_t)b * 2 * I + I + c) * T + t];
+  const int64_t o = ((int64_t)b * I + c) * T + t;
+  const float v = noise ? m + noise[o] * expf(lg) : m;
+  z[o] = t < lens[b] ? v : 0.f;
+}
+
+void launch_posterior_sample(const float* stats, const float* noise, const int* lens, float* z, int B,
+                             int I, int T, hipStream_t s) {
+  dim3 grid((T + 127) / 128, I, B);
+  hipLaunchKernelGGL(posterior_sample_kernel, grid, dim3(128), 0, s, stats, noise, lens, z, I, T);
+}
+
+__global__ void sequence_mask_kernel(const int* lens, float* mask, int T) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T) mask[(int64_t)b * T + t] = t < lens[b] ? 1.f : 0.f;
+}
+
+void launch_sequence_mask(const int* lens, float* mask, int B, int T, hipStream_t s) {
+  hipLaunchKernelGGL(sequence_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, lens, mask, T);
+}
+
+__global__ void lens_to_i32_kernel(const int64_t* lens, int* out, int B, int T, int* bad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const long long l = lens[b];
+  out[b] = l < 0 ? 0 : (l > T ? T : (int)l);
+  bad[b] = (l < 0 || l > T) ? 1 : 0;
+}
+
+void launch_lens_to_i32(const int64_t* lens, int* out, int B, int T, int* bad, hipStream_t s) {
+  hipLaunchKernelGGL(lens_to_i32_kernel, dim3((B + 63) / 64), dim3(64), 0, s, lens, out, B, T, bad);
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -5,8 +5,7 @@ reference (`models.py:573-599`, `697-737`, `742-788`, `.dec` `344-377`), same
 state-dict keys (so `utils.load_checkpoint` and reference checkpoints work),
 but every forward computation happens in the gfx950 kernels behind
 `libmbistft_vits.so`.  PyTorch is used for device memory, the current HIP
-stream and the RNG only.  Training-side methods (`forward`,
-`voice_conversion`) and `enc_q` are out of scope and raise.
+stream and the RNG only.  The training-side `forward` is out of scope and raises.
 """
 import ctypes as C
 import weakref
@@ -180,6 +179,7 @@ class SynthesizerTrn(nn.Module):
             c.n_vocab, c.inter_channels, c.hidden_channels = cfg.n_vocab, cfg.inter_channels, cfg.hidden_channels
             c.filter_channels, c.n_heads, c.n_layers = cfg.filter_channels, cfg.n_heads, cfg.n_layers
             c.kernel_size, c.upsample_initial_channel = cfg.kernel_size, cfg.upsample_initial_channel
+            c.spec_channels = cfg.spec_channels
             for j in range(3):
                 c.resblock_kernel_sizes[j] = cfg.resblock_kernel_sizes[j]
                 for q, d in enumerate(cfg.resblock_dilation_sizes[j]):
@@ -445,6 +445,36 @@ class SynthesizerTrn(nn.Module):
         raise NotImplementedError("training forward (models.py:657-695) is outside the inference "
                                   "hot path this package implements")
 
-    def voice_conversion(self, *a, **k):
-        raise NotImplementedError("voice_conversion (models.py:790-798) needs the posterior encoder, "
-                                  "which is outside the inference hot path (SURVEY §8f rank 4)")
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+        """-> (o_hat, o_hat_mb, y_mask, (z, z_p, z_hat))  (models.py:790-798)."""
+        if not self.n_speakers > 0:
+            raise AssertionError("n_speakers have to be larger than 0.")      # models.py:791
+        h = self._ensure_handle()
+        dev = self._device()
+        cfg = self.cfg
+        if y.dim() != 3 or y.shape[1] != cfg.spec_channels:
+            raise ValueError("y must be [B, %d, T] (linear spectrogram)" % cfg.spec_channels)
+        y = y.to(device=dev, dtype=torch.float32).contiguous()
+        B, _, T = y.shape
+        y_lengths = y_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        sid_src = sid_src.to(device=dev, dtype=torch.int64).contiguous()
+        sid_tgt = sid_tgt.to(device=dev, dtype=torch.int64).contiguous()
+        I = cfg.inter_channels
+        f32 = dict(device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            noise = torch.randn(B, I, T, **f32)                  # randn_like(m) of models.py:245
+            o, o_mb, spec, phase = self._alloc_decoder_outputs(B, T, dev)
+            y_mask = torch.empty(B, 1, T, **f32)
+            z, z_p, z_hat = (torch.empty(B, I, T, **f32) for _ in range(3))
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            out = _capi.MbvOutputs()
+            out.o, out.spec, out.phase = o.data_ptr(), spec.data_ptr(), phase.data_ptr()
+            out.o_mb = o_mb.data_ptr() if o_mb is not None else None
+            out.y_mask, out.z, out.z_p, out.m_p = y_mask.data_ptr(), z.data_ptr(), z_p.data_ptr(), z_hat.data_ptr()
+            _capi.check(h, _capi.lib().mbv_voice_conversion(
+                h, self._ptr(y), self._ptr(y_lengths), self._ptr(sid_src), self._ptr(sid_tgt), B, T,
+                self._ptr(noise), C.byref(out), self._ptr(status), self._stream()), "mbv_voice_conversion")
+            if bool(status.any()):
+                raise IndexError("index out of range in self (y_lengths or speaker id)")
+        return o, o_mb, y_mask, (z, z_p, z_hat)

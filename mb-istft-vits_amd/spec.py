@@ -3,8 +3,8 @@
 The key names and shapes are the checkpoint contract of the reference
 (`models.py:573-655` builds the modules; old-style ``weight_norm`` gives the
 ``*.weight_g`` / ``*.weight_v`` pairs).  Only the modules
-`SynthesizerTrn.infer` touches are listed: ``enc_q`` (posterior encoder,
-`models.py:646`) is training-only and has no entry.
+inference entry points touch are listed (`infer`, `dec`, `voice_conversion`): the
+discriminators and the SDP are training-only / unused and have no entry.
 """
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -21,12 +21,14 @@ DP_KERNEL = 3            # models.py:652
 FLOW_KERNEL = 5          # models.py:647
 FLOW_WN_LAYERS = 4       # models.py:647
 FLOW_N = 4               # models.py:191
+ENC_Q_LAYERS = 16        # models.py:646
 PQMF_TAPS = 62           # pqmf.py:53
 
 
 @dataclass
 class ModelConfig:
     n_vocab: int
+    spec_channels: int = 513         # filter_length // 2 + 1: input of enc_q (voice conversion)
     inter_channels: int = 192
     hidden_channels: int = 192
     filter_channels: int = 768
@@ -121,7 +123,7 @@ def config_from_ctor(n_vocab, spec_channels, segment_size, inter_channels, hidde
     else:
         raise ValueError("Decoder Error in json file")  # models.py:644 prints this
     cfg = ModelConfig(
-        n_vocab=int(n_vocab), inter_channels=int(inter_channels),
+        n_vocab=int(n_vocab), spec_channels=int(spec_channels), inter_channels=int(inter_channels),
         hidden_channels=int(hidden_channels), filter_channels=int(filter_channels),
         n_heads=int(n_heads), n_layers=int(n_layers), kernel_size=int(kernel_size),
         resblock=str(resblock), resblock_kernel_sizes=[int(k) for k in resblock_kernel_sizes],
@@ -199,6 +201,25 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     if cfg.decoder == DEC_MS:
         s["dec.multistream_conv_post.weight_g"] = (1, 1, 1)
         s["dec.multistream_conv_post.weight_v"] = (1, cfg.subbands, PQMF_TAPS + 1)
+    # --- enc_q (PosteriorEncoder, models.py:217-246: 16 WN layers, k5) ----
+    # read by voice_conversion only, but part of every reference checkpoint
+    s["enc_q.pre.weight"] = (H, cfg.spec_channels, 1)
+    s["enc_q.pre.bias"] = (H,)
+    for l in range(ENC_Q_LAYERS):
+        s["enc_q.enc.in_layers.%d.bias" % l] = (2 * H,)
+        s["enc_q.enc.in_layers.%d.weight_g" % l] = (2 * H, 1, 1)
+        s["enc_q.enc.in_layers.%d.weight_v" % l] = (2 * H, H, 5)
+    for l in range(ENC_Q_LAYERS):
+        rs = 2 * H if l < ENC_Q_LAYERS - 1 else H
+        s["enc_q.enc.res_skip_layers.%d.bias" % l] = (rs,)
+        s["enc_q.enc.res_skip_layers.%d.weight_g" % l] = (rs, 1, 1)
+        s["enc_q.enc.res_skip_layers.%d.weight_v" % l] = (rs, H, 1)
+    if gin:
+        s["enc_q.enc.cond_layer.bias"] = (2 * H * ENC_Q_LAYERS,)
+        s["enc_q.enc.cond_layer.weight_g"] = (2 * H * ENC_Q_LAYERS, 1, 1)
+        s["enc_q.enc.cond_layer.weight_v"] = (2 * H * ENC_Q_LAYERS, gin, 1)
+    s["enc_q.proj.weight"] = (2 * I, H, 1)
+    s["enc_q.proj.bias"] = (2 * I,)
     # --- flow (models.py:184-214, modules.py:111-184, 308-353) ------------
     for f in range(FLOW_N):
         p = "flow.flows.%d." % (2 * f)       # odd indices are parameter-free Flip

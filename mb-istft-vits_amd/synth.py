@@ -39,6 +39,8 @@ def _v_std(name: str, shape, cfg: ModelConfig) -> float:
     co, ci, k = shape
     fan_in = ci * k
     std = 1.0 / np.sqrt(fan_in)
+    if name == "enc_q.pre.weight":
+        std *= 0.3                                  # linear-spectrogram magnitudes are O(1..10)
     if name.endswith("post.weight") and name.startswith("flow."):
         std *= 0.5
     if ".cond" in name:
@@ -85,7 +87,7 @@ def make_state_dict(cfg: ModelConfig, seed: int = 1234):
             sd[name] = _normal(name, seed, shape, 0.05)
         elif name.endswith(".weight"):
             w = _normal(name, seed, shape, _v_std(name, shape, cfg))
-            if name == "enc_p.proj.weight":
+            if name in ("enc_p.proj.weight", "enc_q.proj.weight"):
                 w[shape[0] // 2:] *= 0.2             # logs_p half: keep exp(logs_p) tame
             sd[name] = w
         else:  # pragma: no cover

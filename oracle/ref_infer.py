@@ -182,20 +182,20 @@ def length_regulate(logw, x_mask, m_p, logs_p, length_scale=1.0, t_frames=None):
 # --------------------------------------------------------------------------
 # reverse flow (models.py:207-214, modules.py:148-176, 334-353)
 # --------------------------------------------------------------------------
-def wn_stack(W, prefix, cfg, h, mask, g=None):
+def wn_stack(W, prefix, cfg, h, mask, g=None, n_layers=FLOW_LAYERS):
     H = cfg.hidden_channels
     out = torch.zeros_like(h)
     gc = None
     if g is not None:
         gc = F.conv1d(g, W.w(prefix + ".cond_layer"), W.b(prefix + ".cond_layer"))  # [B,2H*L,1]
-    for l in range(FLOW_LAYERS):
+    for l in range(n_layers):
         a = conv_same(h, W.w(prefix + ".in_layers.%d" % l), W.b(prefix + ".in_layers.%d" % l))
         if gc is not None:
             a = a + gc[:, 2 * H * l:2 * H * (l + 1)]
         acts = torch.tanh(a[:, :H]) * torch.sigmoid(a[:, H:])     # commons.py:100-107
         rs = F.conv1d(acts, W.w(prefix + ".res_skip_layers.%d" % l),
                       W.b(prefix + ".res_skip_layers.%d" % l))
-        if l < FLOW_LAYERS - 1:
+        if l < n_layers - 1:
             h = (h + rs[:, :H]) * mask
             out = out + rs[:, H:]
         else:
@@ -218,6 +218,51 @@ def flow_reverse(W, cfg, z_p, y_mask, g=None, taps=None):
         if taps is not None:
             taps["flow_after_%d" % f] = x
     return x
+
+
+def flow_forward(W, cfg, z, y_mask, g=None):
+    """models.py:209-210: coupling layer then Flip, flows 0..3 (mean_only: logs = 0)."""
+    half = cfg.inter_channels // 2
+    x = z
+    for f in range(N_FLOWS):
+        p = "flow.flows.%d" % (2 * f)
+        x0, x1 = x[:, :half], x[:, half:]
+        h = F.conv1d(x0, W.w(p + ".pre"), W.b(p + ".pre")) * y_mask
+        h = wn_stack(W, p + ".enc", cfg, h, y_mask, g)
+        m = F.conv1d(h, W.w(p + ".post"), W.b(p + ".post")) * y_mask
+        x = torch.cat([x0, m + x1 * y_mask], 1)                  # modules.py:345
+        x = torch.flip(x, [1])
+    return x
+
+
+def posterior_encoder(W, cfg, y, y_lengths, g, noise):
+    """models.py:239-246.  `noise` replaces torch.randn_like(m)."""
+    mask = sequence_mask(y_lengths, y.shape[2])
+    h = F.conv1d(y, W.w("enc_q.pre"), W.b("enc_q.pre")) * mask
+    h = wn_stack(W, "enc_q.enc", cfg, h, mask, g, n_layers=16)
+    stats = F.conv1d(h, W.w("enc_q.proj"), W.b("enc_q.proj")) * mask
+    m, logs = stats[:, :cfg.inter_channels], stats[:, cfg.inter_channels:]
+    z = (m + (noise * torch.exp(logs) if noise is not None else 0.0)) * mask
+    return z, m, logs, mask
+
+
+def voice_conversion(sd, cfg, y, y_lengths, sid_src, sid_tgt, noise=None):
+    """models.py:790-798 -> dict(o, o_mb, y_mask, z, z_p, z_hat)."""
+    W = sd if isinstance(sd, Weights) else Weights(sd)
+    y = torch.as_tensor(y).float()
+    y_lengths = torch.as_tensor(y_lengths).long()
+    with torch.no_grad():
+        g_src = W["emb_g.weight"][torch.as_tensor(sid_src).long()].unsqueeze(-1)
+        g_tgt = W["emb_g.weight"][torch.as_tensor(sid_tgt).long()].unsqueeze(-1)
+        z, _, _, y_mask = posterior_encoder(W, cfg, y, y_lengths, g_src,
+                                            torch.as_tensor(noise) if noise is not None else None)
+        z_p = flow_forward(W, cfg, z, y_mask, g_src)
+        z_hat = flow_reverse(W, cfg, z_p, y_mask, g_tgt)
+        o, o_mb, _, _ = decode(W, cfg, z_hat * y_mask, g_tgt)
+    out = dict(o=o, y_mask=y_mask, z=z, z_p=z_p, z_hat=z_hat)
+    if o_mb is not None:
+        out["o_mb"] = o_mb
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -125,6 +125,40 @@ CASES = [
 ]
 
 
+def make_voice_conversion_golden(models, utils):
+    """SynthesizerTrn.voice_conversion (models.py:790-798) on the multi-speaker config; the
+    posterior encoder's randn_like draw is pinned by patching it for the duration of the call."""
+    import torch
+    from mb_istft_vits_amd import synth, spec as mspec, utils as mutils
+    cfg_name, n_vocab, B, T = "uudb_ms_istft_vits_ms", 59, 2, 26
+    hps, net = build_reference_model(models, utils, cfg_name, n_vocab)
+    my_hps = mutils.get_hparams_from_file(mutils.builtin_config(cfg_name))
+    cfg = mspec.config_from_ctor(n_vocab, my_hps.data.filter_length // 2 + 1,
+                                 my_hps.train.segment_size // my_hps.data.hop_length,
+                                 n_speakers=my_hps.data.n_speakers, **my_hps.model)
+    sd = synth.make_state_dict(cfg, 1234)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rs = np.random.RandomState(77)
+    y = np.abs(rs.standard_normal((B, 513, T))).astype(np.float32) * 2.0       # magnitude spectrogram
+    yl = np.asarray([26, 17], np.int64)
+    sid_src, sid_tgt = np.asarray([3, 9], np.int64), np.asarray([7, 0], np.int64)
+    noise = rs.standard_normal((B, 192, T)).astype(np.float32)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: torch.from_numpy(noise) if tuple(t.shape) == noise.shape else real(t, **k)
+    try:
+        with torch.no_grad():
+            o, o_mb, y_mask, (z, z_p, z_hat) = net.voice_conversion(
+                torch.from_numpy(y), torch.from_numpy(yl), torch.from_numpy(sid_src), torch.from_numpy(sid_tgt))
+    finally:
+        torch.randn_like = real
+    np.savez_compressed(os.path.join(HERE, "vc_uudb_b2.npz"), y=y, y_lengths=yl, sid_src=sid_src,
+                        sid_tgt=sid_tgt, noise=noise, o=o.numpy(), o_mb=o_mb.numpy(), y_mask=y_mask.numpy(),
+                        z=z.numpy(), z_p=z_p.numpy(), z_hat=z_hat.numpy(), weight_seed=np.int64(1234),
+                        n_vocab=np.int64(n_vocab))
+    print("vc_uudb_b2  o", tuple(o.shape), "|o|rms=%.4f" % float(o.pow(2).mean().sqrt()),
+          "%.0f KB" % (os.path.getsize(os.path.join(HERE, "vc_uudb_b2.npz")) / 1024))
+
+
 def main():
     import torch
     from mb_istft_vits_amd import synth, spec as mspec, utils as mutils
@@ -149,7 +183,7 @@ def main():
         while True:
             sd = synth.make_state_dict(cfg, seed)
             full = net.state_dict()
-            missing = [k for k in full if not k.startswith("enc_q") and k not in sd]
+            missing = [k for k in full if k not in sd]
             extra = [k for k in sd if k not in full]
             assert not missing and not extra, (missing[:5], extra[:5])
             for k, v in sd.items():
@@ -183,6 +217,8 @@ def main():
             fixture, cfg_name, seed, taps["z"].shape[-1], tuple(taps["o"].shape),
             float(taps["o"].pow(2).mean().sqrt()), margin, size / 1024))
 
+    if not only or "vc_uudb_b2" in only:
+        make_voice_conversion_golden(models, utils)
     if only and "signal_ops" not in only:
         return
     # ---- stand-alone known-answer vectors for the signal ops -------------

@@ -231,3 +231,29 @@ def test_full_size_batch64_properties():
     got = o[[3, 57]].cpu().numpy()
     assert np.array_equal(ylen[[3, 57]].cpu().numpy(), ref["y_lengths"].numpy())
     assert rms(got - ref["o"].numpy()) < 1e-4
+
+
+def test_voice_conversion_matches_reference_golden():
+    """`voice_conversion` (models.py:790-798) against the vector captured from the reference; the
+    posterior encoder's noise draw is pinned by seeding torch and recovering it is not possible, so
+    the shim's RNG is patched to hand the golden noise to the kernel."""
+    from gpu_util import make_net
+    gold = load_fixture("vc_uudb_b2")
+    net, sd = make_net("uudb_ms_istft_vits_ms", int(gold["n_vocab"]), int(gold["weight_seed"]))
+    noise = torch.from_numpy(gold["noise"]).cuda()
+    real = torch.randn
+    torch.randn = lambda *a, **k: noise if tuple(a) == tuple(noise.shape) else real(*a, **k)
+    try:
+        o, o_mb, y_mask, (z, z_p, z_hat) = net.voice_conversion(
+            torch.from_numpy(gold["y"]).cuda(), torch.from_numpy(gold["y_lengths"]).cuda(),
+            torch.from_numpy(gold["sid_src"]).cuda(), torch.from_numpy(gold["sid_tgt"]).cuda())
+    finally:
+        torch.randn = real
+    assert np.array_equal(y_mask.cpu().numpy(), gold["y_mask"])
+    for name, t in dict(z=z, z_p=z_p, z_hat=z_hat, o_mb=o_mb, o=o).items():
+        assert t.shape == gold[name].shape, name
+        assert _rel(t.cpu().numpy(), gold[name]) < 5e-5, (name, _rel(t.cpu().numpy(), gold[name]))
+    assert rms(o.cpu().numpy() - gold["o"]) < 1e-4
+    with pytest.raises(IndexError):
+        net.voice_conversion(torch.from_numpy(gold["y"]).cuda(), torch.from_numpy(gold["y_lengths"]).cuda(),
+                             torch.tensor([3, 12]).cuda(), torch.tensor([0, 1]).cuda())

@@ -167,6 +167,7 @@ def test_c_abi_error_paths(net):
     c.struct_bytes = C.sizeof(_capi.MbvConfig)
     c.n_vocab, c.inter_channels, c.hidden_channels, c.filter_channels = 59, 192, 96, 768
     c.n_heads, c.n_layers, c.kernel_size, c.upsample_initial_channel = 2, 3, 3, 256
+    c.spec_channels = 513
     for j, k in enumerate((3, 7, 11)):
         c.resblock_kernel_sizes[j] = k
         for q, d in enumerate((1, 3, 5)):
@@ -193,7 +194,7 @@ def test_c_abi_error_paths(net):
         shp = (C.c_int64 * 2)(59, 95)
         assert L.mbv_load_weight(h, b"enc_p.emb.weight", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
         assert b"shape mismatch" in L.mbv_last_error(h)
-        assert L.mbv_load_weight(h, b"enc_q.pre.weight", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
+        assert L.mbv_load_weight(h, b"net_d.conv.weight", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
         assert b"not a weight of the infer path" in L.mbv_last_error(h)
         shp = (C.c_int64 * 2)(59, 96)
         w = np.zeros((59, 96), np.float32)

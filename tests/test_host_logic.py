@@ -35,8 +35,8 @@ def test_header_symbols_all_exported():
 
 
 def test_config_struct_layout_matches_header():
-    # 9 scalars + 3 kernel sizes + 9 dilations + resblock_type + 4 trailing scalars, all int32
-    assert C.sizeof(_capi.MbvConfig) == 4 * (9 + 3 + 9 + 1 + 4)
+    # 10 scalars + 3 kernel sizes + 9 dilations + resblock_type + 4 trailing scalars, all int32
+    assert C.sizeof(_capi.MbvConfig) == 4 * (10 + 3 + 9 + 1 + 4)
     assert C.sizeof(_capi.MbvOutputs) == 8 * 10
 
 
@@ -51,6 +51,7 @@ def test_create_fails_loudly_without_gpu_or_with_bad_config():
         c.struct_bytes = C.sizeof(_capi.MbvConfig)
         c.n_vocab, c.inter_channels, c.hidden_channels, c.filter_channels = 59, 192, 192, 768
         c.n_heads, c.n_layers, c.kernel_size, c.upsample_initial_channel = 2, 6, 3, 512
+        c.spec_channels = 513
         for j, k in enumerate((3, 7, 11)):
             c.resblock_kernel_sizes[j] = k
             for q, d in enumerate((1, 3, 5)):
@@ -68,9 +69,9 @@ def test_state_dict_keys_match_reference_contract():
         assert keys == list(want.keys())
         for k, t in net.state_dict().items():
             assert tuple(t.shape) == tuple(want[k]), k
-    # counts probed from the reference in SURVEY §8a (uudb: 383 non-enc_q keys)
+    # counts probed from the reference (uudb has 383 keys outside enc_q, + 103 in enc_q)
     _, net = _net("uudb_ms_istft_vits_ms")
-    assert len(net.state_dict()) == 383
+    assert len(net.state_dict()) == 383 + 103
     assert hasattr(net, "emb_g") and net.n_speakers == 12 and callable(net.dec)
 
 
@@ -79,7 +80,7 @@ def test_load_checkpoint_is_key_tolerant(tmp_path):
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     dropped = "dec.conv_pre.bias"
     saved = {k: v + 1.0 for k, v in sd.items() if k != dropped}
-    saved["enc_q.pre.weight"] = torch.zeros(3)             # training-only key in real checkpoints
+    saved["dummy_discriminator.weight"] = torch.zeros(3)   # keys the model does not have are ignored
     path = tmp_path / "G_1.pth"
     torch.save({"model": saved, "iteration": 7, "optimizer": None, "learning_rate": 2e-4}, path)
     m, opt, lr, it = utils.load_checkpoint(str(path), net, None)
@@ -121,7 +122,7 @@ def test_cpu_model_raises_instead_of_falling_back():
         net.infer(torch.zeros(1, 4, dtype=torch.long), torch.tensor([4]))
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         net.dec(torch.zeros(1, 192, 4))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                  # single-speaker model (models.py:791)
         net.voice_conversion(None, None, None, None)
 
 

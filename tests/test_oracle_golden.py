@@ -49,3 +49,17 @@ def test_signal_ops_known_answers():
     sub = torch.from_numpy(g["pqmf_in"])
     full = R.synthesis_filter_apply(R.zero_stuff(sub), torch.from_numpy(R.pqmf_synthesis_filter()))
     assert np.abs(full.numpy() - g["pqmf_out"]).max() < 5e-6
+
+
+def test_voice_conversion_matches_reference():
+    """`SynthesizerTrn.voice_conversion` (models.py:790-798) with the posterior noise pinned."""
+    gold = load_fixture("vc_uudb_b2")
+    _, cfg = config_for("uudb_ms_istft_vits_ms", int(gold["n_vocab"]))
+    sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
+    torch.set_num_threads(4)
+    out = R.voice_conversion(sd, cfg, gold["y"], gold["y_lengths"], gold["sid_src"], gold["sid_tgt"],
+                             noise=gold["noise"])
+    for name in ("y_mask", "z", "z_p", "z_hat", "o_mb", "o"):
+        got, ref = out[name].numpy(), gold[name]
+        assert got.shape == ref.shape, name
+        assert rms(got - ref) <= 2e-5 * max(rms(ref), 1e-3) + 1e-6, name
