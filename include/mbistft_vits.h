@@ -91,7 +91,8 @@ const char *mbv_last_error(const mbv_model *m);
  * replaces nn.Module.load_state_dict as used by utils.load_checkpoint
  * (utils.py:22-47).  `name` is the reference state-dict key
  * ("dec.ups.0.weight_v", …); `data` is a HOST pointer to fp32 values of
- * `shape[0..ndim)`.  Keys outside the infer path (enc_q.*) are rejected.
+ * `shape[0..ndim)`.  Keys the inference entry points never read (discriminators, SDP) are
+ * rejected; enc_q.* is accepted (voice conversion).
  * mbv_finalize_weights folds weight-norm (w = g v/||v||),
  * packs every conv for the kernels, uploads once, and may be called again
  * after further mbv_load_weight calls.  It synchronises `stream`. */
