@@ -44,12 +44,21 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // NWN = waves along time.  NWN == 2: 256 threads, single LDS buffer, 2 barriers per chunk,
-// several workgroups per CU (short sequences / small launches).  NWN == 4: 512 threads = one
+// two workgroups per CU (short sequences / small launches).  NWN == 4: 512 threads = one
 // workgroup per CU with 2 waves per SIMD, the weight slab shared by twice as many columns,
 // DOUBLE-buffered LDS: chunk c+1 is committed into the other buffer right after the MFMA loop of
 // chunk c, one barrier per chunk, waves drift apart instead of staging in lockstep.
-template <int WM, int WN, int CK, int NWN>
-__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kernel(const ConvArgs a) {
+//
+// Persistent tiles: the grid is at most the number of workgroups resident on the chip; each
+// workgroup walks output tiles blockIdx.x, blockIdx.x + gridDim.x, ... and treats the chunks of all
+// its tiles as ONE staging stream: chunk 0 of the next tile is loaded and committed to LDS while the
+// last chunk of the current tile is in the MFMA loop.  The epilogue (residual reads + output stores;
+// with one workgroup per CU it used to run with the matrix pipe idle: measured 25 % of a k=3 conv)
+// is then followed immediately by MFMA work on data already in LDS, so its stores drain underneath.
+// No staging registers are live across the epilogue.
+template <int WM, int WN, int CK, int NWN, int EPI>
+__global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
+                                                                   int tiles_y, int total_tiles) {
   constexpr int NT = 128 * NWN;          // threads
   constexpr bool DB = NWN == 4;          // double-buffered LDS
   constexpr int BM = 64 * WM;            // 2 waves x WM tiles of 32 rows
@@ -62,34 +71,12 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
   const int wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int hl = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z;
-  const int m0 = blockIdx.y * BM;
-  const int t0 = blockIdx.x * BN;
 
   const int halo = (a.K - 1) * a.dil;
   const int XL = BN + halo;                            // staged columns
   // one LDS buffer: input image [G][2][XL] + weight slab [K][G][2][BM] (+ 2*BM prefetch overrun)
   const int buf_f4 = G * 2 * XL + a.K * G * 2 * BM + 2 * BM;
   f32x4* const lds4 = reinterpret_cast<f32x4*>(lds);
-
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // number of this wave's 32-row tiles that hold real rows (wave-uniform)
-  const int wrow0 = m0 + wm * 32 * WM;
-  int nact = (a.M - wrow0 + 31) / 32;
-  nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
-  // ... and of its 32-column tiles that start inside the sequence (ragged last block)
-  int nj = (a.T - (t0 + wn * 32 * WN) + 31) / 32;
-  nj = nj < 0 ? 0 : (nj > WN ? WN : nj);
-
-  const float* xb = a.x + (int64_t)b * a.x_bstride;
-  const int len_in = a.in_lens ? a.in_lens[b] : 0x7fffffff;
   const int tin_eff = a.reflect1 ? a.Tin + 1 : a.Tin;  // length of the (virtually padded) input
 
   // ---- async-stage bookkeeping ------------------------------------------------
@@ -102,44 +89,47 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
   static_assert(RPI % ROWS_PER_TAP == 0 || ROWS_PER_TAP % RPI == 0, "weight-row decomposition");
   f32x4 wreg[NW];
   f32x4 xreg[NXP];
+  int xoff[NXP];
   const int totalW = a.K * ROWS_PER_TAP * BM;                  // float4 in the slab
-
-  // Weight slab: global order == LDS order ([tap][Cin/8][2][Mpad][4] vs [tap][G][2][BM][4]);
-  // thread copies float4 (row R_0 + u*RPI, column wq).  Pass u differs from pass 0 by a
-  // wave-uniform element offset (saddr-form loads).
   const int wq = tid % BM, wR0 = tid / BM;
   const int wtap0 = RPI >= ROWS_PER_TAP ? wR0 / ROWS_PER_TAP : 0;
   const int wrem0 = RPI >= ROWS_PER_TAP ? wR0 % ROWS_PER_TAP : wR0;
   const int64_t tap_stride = (int64_t)(a.Cin / 8) * 2 * a.Mpad * 4;       // floats per tap
-  const float* wlane = a.w + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + m0 + wq) * 4;
+  const int nchunks = (a.debug == 1 || a.debug == 4) ? 1 : a.Cin / CK;   // debug: stage chunk 0 only (timing)
 
+  // per-tile load descriptors (of the tile whose chunks are being staged)
+  int lb = 0, lm0 = 0, lt0 = 0;
+  const float* wlane = nullptr;          // weight slab: lane base, pass u adds a wave-uniform offset
+  const float* xb = nullptr;
+
+  // Weight slab: global order == LDS order ([tap][Cin/8][2][Mpad][4] vs [tap][G][2][BM][4]);
+  // thread copies float4 (row R_0 + u*RPI, column wq).
   // Input window: item e = tid + NT u -> (P = group*2 + h, col); its four K-steps are the
-  // channels 8 g + h + 2 s.  Offset of s = 0 inside a chunk, -1 = zero padding / masked.
-  int xoff[NXP];
-  {
-    int P = tid / XL, col = tid - P * XL;
-#pragma unroll
-    for (int u = 0; u < NXP; ++u) {
-      int off = -1;
-      if (P < 2 * G) {
-        int gi = t0 - a.pad_left + col;
-        if (gi >= 0 && gi < tin_eff) {
-          if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;
-          if (gi < len_in) off = ((P >> 1) * 8 + (P & 1)) * a.x_rstride + gi;
-        }
-      }
-      xoff[u] = off;
-      col += NT;
-#pragma unroll
-      for (int w = 0; w < NT / 128; ++w)
-        if (col >= XL) { col -= XL; ++P; }
-    }
+  // channels 8 g + h + 2 s.  xoff = offset of s = 0 inside a chunk, -1 = zero padding / masked.
+#define MBV_SETUP_TILE(TILE)                                                                 \
+  {                                                                                          \
+    const int tile_ = (TILE);                                                                \
+    const int tx_ = tile_ % tiles_x, rest_ = tile_ / tiles_x;                                \
+    lb = rest_ / tiles_y; lm0 = (rest_ % tiles_y) * BM; lt0 = tx_ * BN;                      \
+    wlane = a.w + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + lm0 + wq) * 4;    \
+    xb = a.x + (int64_t)lb * a.x_bstride;                                                    \
+    const int len_in_ = a.in_lens ? a.in_lens[lb] : 0x7fffffff;                              \
+    int P = tid / XL, col = tid - P * XL;                                                    \
+    _Pragma("unroll") for (int u = 0; u < NXP; ++u) {                                        \
+      int off = -1;                                                                          \
+      if (P < 2 * G) {                                                                       \
+        int gi = lt0 - a.pad_left + col;                                                     \
+        if (gi >= 0 && gi < tin_eff) {                                                       \
+          if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;                                         \
+          if (gi < len_in_) off = ((P >> 1) * 8 + (P & 1)) * a.x_rstride + gi;               \
+        }                                                                                    \
+      }                                                                                      \
+      xoff[u] = off;                                                                         \
+      col += NT;                                                                             \
+      _Pragma("unroll") for (int w = 0; w < NT / 128; ++w)                                   \
+        if (col >= XL) { col -= XL; ++P; }                                                   \
+    }                                                                                        \
   }
-
-  // Loop body, entered first with ci0 = -CK (no compute).  Single buffer (NWN == 2):
-  //   issue(c+1) | MFMA(c) | barrier | commit(c+1) | barrier
-  // Double buffer (NWN == 4): registers hold chunk c+1 on entry,
-  //   MFMA(c) from buf[c&1] | commit(c+1) -> buf[(c+1)&1] | issue(c+2) | barrier
 #define MBV_ISSUE(CN)                                                                        \
   {                                                                                          \
     const int cn_ = (CN);                                                                    \
@@ -183,7 +173,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
         if (xoff[u] >= 0) {                                                                  \
           v = xreg[u];                                                                       \
           if (a.chan_add) {                                                                  \
-            const float* ca = a.chan_add + b * a.Cin + cn_ + (P >> 1) * 8 + (P & 1);         \
+            const float* ca = a.chan_add + lb * a.Cin + cn_ + (P >> 1) * 8 + (P & 1);        \
             v[0] += ca[0]; v[1] += ca[2]; v[2] += ca[4]; v[3] += ca[6];                      \
           }                                                                                  \
           _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu(v[s4], a.in_slope); \
@@ -196,49 +186,129 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
     }                                                                                        \
   }
 
-  const int nchunks = a.debug == 1 ? 1 : a.Cin / CK;          // debug 1: stage chunk 0 only (timing)
-  if constexpr (DB) { MBV_ISSUE(0); }
-  for (int ci0 = -CK; ci0 < a.Cin; ci0 += CK) {
-    const int c = ci0 / CK;                                   // -1 on the priming pass
-    const bool more = c + 1 < nchunks;                        // chunk c+1 exists
-    const int cn = ci0 + CK;
-    f32x4* const Xs = lds4 + (DB ? ((c & 1) ? buf_f4 : 0) : 0);           // buffer holding chunk c
-    f32x4* const Ws = Xs + G * 2 * XL;
-    f32x4* const Xn = lds4 + (DB ? ((c & 1) ? 0 : buf_f4) : 0);           // buffer for chunk c+1
-    f32x4* const Wn = Xn + G * 2 * XL;
-    if constexpr (!DB) {
-      if (more) { MBV_ISSUE(cn); }
-    }
+  // staging cursor: the next chunk to load (runs ahead of the tile being multiplied)
+  const int nck = a.Cin / CK;
+  const bool stage0_only = a.debug == 1 || a.debug == 4;      // timing experiments: stage chunk 0 of a tile only
+  int s_tile = blockIdx.x, s_c = 0;
+  int pend_cn = -1;                      // channel offset of the chunk held in wreg/xreg (-1: none)
+#define MBV_ISSUE_NEXT()                                                                     \
+  if (s_tile < total_tiles) {                                                                \
+    if (s_c == 0) MBV_SETUP_TILE(s_tile);                                                    \
+    if (s_c == 0 || !stage0_only) {                                                          \
+      MBV_ISSUE(s_c * CK);                                                                   \
+      pend_cn = s_c * CK;                                                                    \
+    }                                                                                        \
+    if (++s_c == nck) { s_c = 0; s_tile += gridDim.x; }                                      \
+  }
 
-    if (ci0 >= 0 && a.debug != 3) {
-      // ---- MFMA over (tap, group) steps; each step = 4 K-steps from one b128 per operand tile
-      const int nsteps = a.K * G;
-      const f32x4* wbase = Ws + hl * BM + wm * 32 * WM + l31;       // + step * 2 * BM
-      const f32x4* xbase = Xs + hl * XL + wn * 32 * WN + l31;       // + g * 2 * XL + tap * dil
-      if (nact == WM) {
-        f32x4 a0[WM], b0[WN];
-        [[maybe_unused]] f32x4 a1[WM], b1[WN];
-#define MBV_LOAD_AB(ST, AV, BV)                                                   \
-        {                                                                          \
-          const int st_ = (ST);                                                    \
-          const int tap_ = st_ / G, g_ = st_ % G;                                  \
-          const f32x4* wp_ = wbase + st_ * (2 * BM);                               \
-          const f32x4* xp_ = xbase + g_ * (2 * XL) + tap_ * a.dil;                 \
-          _Pragma("unroll") for (int i = 0; i < WM; ++i) AV[i] = wp_[i * 32];      \
-          _Pragma("unroll") for (int j = 0; j < WN; ++j) BV[j] = xp_[j * 32];      \
+  // ---- prime: chunk 0 of the first tile -> LDS buffer 0 -------------------------
+  MBV_ISSUE_NEXT();
+  {
+    f32x4* const X0 = lds4;
+    f32x4* const W0 = X0 + G * 2 * XL;
+    if (pend_cn >= 0) { MBV_COMMIT(pend_cn, X0, W0); }
+    pend_cn = -1;
+  }
+  __syncthreads();
+
+  int q = 0;                             // chunks multiplied so far (LDS buffer parity)
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, rest = tile / tiles_x;
+    const int b = rest / tiles_y, m0 = (rest % tiles_y) * BM, t0 = tx * BN;
+    const int wrow0 = m0 + wm * 32 * WM;
+    int nact = (a.M - wrow0 + 31) / 32;              // 32-row tiles of this wave that hold real rows
+    nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
+    int nj = (a.T - (t0 + wn * 32 * WN) + 31) / 32;  // ... and 32-column tiles inside the sequence
+    nj = nj < 0 ? 0 : (nj > WN ? WN : nj);
+
+    // Accumulators start from everything the epilogue would otherwise have to READ after the MFMA
+    // loop (residual, running ResBlock sum, the tensor a flow layer updates in place).  gfx9 counts
+    // loads and stores on one in-order counter, so a load issued after a store waits for that store
+    // to reach L2: an epilogue that interleaves the two is a chain of round trips (measured: a
+    // quarter of a k=3 conv).  With the reads up here the epilogue is stores only.
+    f32x16 acc[WM][WN];
+    constexpr bool kInit = EPI == EPI_RESID || EPI == EPI_RESID_ACC || EPI == EPI_RES_SKIP || EPI == EPI_COUPLE;
+    // bias (+ per-utterance row terms) of row wrow0 + lane, handed out by cross-lane reads below
+    float rowc = 0.f;
+    {
+      const int row = wrow0 + lane;
+      if constexpr (EPI == EPI_GATE) {
+        // packed (tanh tile, sigmoid tile) pairs: lane < 32 -> tanh row of channel cbase + lane
+        const int ch = (wrow0 >> 6) * 32 + l31;
+        if (lane < 32 * WM && ch < a.gate_half) {
+          const int idx = hl ? a.gate_half + ch : ch;
+          rowc = a.bias ? a.bias[idx] : 0.f;
+          if (a.gate_cond) rowc += a.gate_cond[(int64_t)b * a.gate_cond_bstride + idx];
         }
+      } else if (lane < 32 * WM && row < a.M) {
+        rowc = a.bias ? a.bias[row] : 0.f;
+        if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC)
+          if (a.res_chan_add) rowc += a.res_chan_add[b * a.M + row];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          float v0 = 0.f;
+          if constexpr (kInit) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
+            if (row < a.M && t < a.T) {
+              if constexpr (EPI == EPI_RESID) {
+                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
+              } else if constexpr (EPI == EPI_RESID_ACC) {
+                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
+                if (a.accum_in) v0 += a.accum_in[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+              } else if constexpr (EPI == EPI_RES_SKIP) {
+                if (row < a.split) v0 = a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+                else if (a.skip_accum) v0 = a.skip[((int64_t)b * (a.M - a.split) + (row - a.split)) * a.T + t];
+              } else {   // EPI_COUPLE: y' = mask * sign * (sign * y + conv + bias)
+                v0 = a.couple_sign * a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+              }
+            }
+          }
+          acc[i][j][r] = v0;
+        }
+      }
+    if constexpr (DB) { MBV_ISSUE_NEXT(); }   // second chunk of this tile (its first is in LDS)
+
+    for (int c = 0; c < nck; ++c, ++q) {
+      f32x4* const Xs = lds4 + (DB ? ((q & 1) ? buf_f4 : 0) : 0);           // buffer holding this chunk
+      f32x4* const Ws = Xs + G * 2 * XL;
+      f32x4* const Xn = lds4 + (DB ? ((q & 1) ? 0 : buf_f4) : 0);           // buffer for the next one
+      f32x4* const Wn = Xn + G * 2 * XL;
+      if constexpr (!DB) { MBV_ISSUE_NEXT(); }       // next chunk (possibly the next tile's first)
+
+      if (a.debug != 3) {
+        // ---- MFMA over (tap, group) steps; each step = 4 K-steps from one b128 per operand tile
+        const int nsteps = a.K * G;
+        const f32x4* wbase = Ws + hl * BM + wm * 32 * WM + l31;       // + step * 2 * BM
+        const f32x4* xbase = Xs + hl * XL + wn * 32 * WN + l31;       // + g * 2 * XL + tap * dil
+        if (nact == WM) {
+          f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
+#define MBV_LOAD_AB(ST, AV, BV)                                                   \
+          {                                                                        \
+            const int st_ = (ST);                                                  \
+            const int tap_ = st_ / G, g_ = st_ % G;                                \
+            const f32x4* wp_ = wbase + st_ * (2 * BM);                             \
+            const f32x4* xp_ = xbase + g_ * (2 * XL) + tap_ * a.dil;               \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) AV[i] = wp_[i * 32];    \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j) BV[j] = xp_[j * 32];    \
+          }
 #define MBV_MMA(AV, BV)                                                            \
-        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                           \
-          _Pragma("unroll") for (int i = 0; i < WM; ++i)                           \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j)                         \
-              if (j < nj)                                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
-        if constexpr (WN < 4) {
-          // operands double-buffered one step ahead (4 accumulators: short steps)
+          _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                         \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                         \
+              _Pragma("unroll") for (int j = 0; j < WN; ++j)                       \
+                if (j < nj)                                                        \
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
+          // operands double-buffered one step ahead; sched_barrier keeps hipcc from sinking the
+          // prefetch back behind the MFMAs
           MBV_LOAD_AB(0, a0, b0);
           int st = 0;
           for (; st + 1 < nsteps; st += 2) {
-            // sched_barrier keeps hipcc from sinking the prefetch back behind the MFMAs
             MBV_LOAD_AB(st + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
             MBV_MMA(a0, b0);
@@ -249,153 +319,156 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 2 : 2) void conv1d_mfma_kerne
             __builtin_amdgcn_sched_barrier(0);
           }
           if (st < nsteps) { MBV_MMA(a0, b0); }                // odd step count
-        } else {
-          // 8 accumulators: 32 MFMAs (2048 pipe cycles) per step hide the next step's LDS
-          // latency behind the co-resident wave; single operand set keeps VGPRs under 256
-          for (int st = 0; st < nsteps; ++st) {
-            MBV_LOAD_AB(st, a0, b0);
-            MBV_MMA(a0, b0);
-          }
-        }
 #undef MBV_LOAD_AB
 #undef MBV_MMA
-      } else if (nact == 1) {                                // only reachable with WM == 2
-        for (int st = 0; st < nsteps; ++st) {
-          const int tap = st / G, g = st % G;
-          const f32x4 av = wbase[st * (2 * BM)];
-          const f32x4* xp = xbase + g * (2 * XL) + tap * a.dil;
+        } else if (nact == 1) {                                // only reachable with WM == 2
+          for (int st = 0; st < nsteps; ++st) {
+            const int tap = st / G, g = st % G;
+            const f32x4 av = wbase[st * (2 * BM)];
+            const f32x4* xp = xbase + g * (2 * XL) + tap * a.dil;
 #pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            const f32x4 bv = xp[j * 32];
+            for (int j = 0; j < WN; ++j) {
+              const f32x4 bv = xp[j * 32];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-              acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bv[s4], acc[0][j], 0, 0, 0);
+              for (int s4 = 0; s4 < 4; ++s4)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s4], bv[s4], acc[0][j], 0, 0, 0);
+            }
           }
+        }
+      }
+
+      // pend_cn and the cursor depend on blockIdx only: the barriers below are workgroup-uniform
+      if constexpr (DB) {
+        if (pend_cn >= 0) { MBV_COMMIT(pend_cn, Xn, Wn); }   // other buffer: last read one barrier ago
+        pend_cn = -1;
+        if (c + 1 < nck) { MBV_ISSUE_NEXT(); }               // the last chunk issues AFTER the epilogue
+        __syncthreads();
+      } else {
+        if (pend_cn >= 0) {
+          __syncthreads();                          // every wave is done reading the buffer
+          MBV_COMMIT(pend_cn, Xn, Wn);
+          pend_cn = -1;
+          __syncthreads();
         }
       }
     }
 
-    if constexpr (DB) {
-      if (more) {
-        MBV_COMMIT(cn, Xn, Wn);                   // other buffer: last read one barrier ago
-        if (c + 2 < nchunks) { MBV_ISSUE(cn + CK); }
+    // ---- epilogue ----------------------------------------------------------
+    // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // stores only (see the accumulator initialisation above)
+    const bool skip_epi = a.debug == 4 && acc[0][0][0] != 12345.678f;   // timing experiment: no epilogue traffic
+    const int T = a.T;
+    const int len_out = a.out_lens ? a.out_lens[b] : 0x7fffffff;
+    if (skip_epi) {
+    } else if constexpr (EPI == EPI_GATE) {
+      if constexpr (WM == 2) {
+        if (nact == 2) {
+          const int cbase = (wrow0 >> 6) * 32;            // channel of packed tile pair
+          float* yb = a.y + (int64_t)b * a.y_bstride;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hl;
+            const float bt = __shfl(rowc, k), bs = __shfl(rowc, 32 + k);
+            const int c = cbase + k;
+            if (c >= a.gate_half) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int t = t0 + wn * 32 * WN + j * 32 + l31;
+              if (t < T) {
+                const float vt = tanhf(acc[0][j][r] + bt);
+                const float vs = sigmoidf_(acc[1][j][r] + bs);
+                yb[(int64_t)c * T + t] = vt * vs;
+              }
+            }
+          }
+        }
       }
-      __syncthreads();
     } else {
-      if (more) {
-        __syncthreads();                          // every wave is done reading the buffer
-        MBV_COMMIT(cn, Xn, Wn);
-        __syncthreads();
-      }
-    }
-  }
-#undef MBV_ISSUE
-#undef MBV_COMMIT
-
-  // ---- epilogue ----------------------------------------------------------
-  // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int T = a.T;
-  const int len_out = a.out_lens ? a.out_lens[b] : 0x7fffffff;
-  if (a.epi == EPI_GATE) {
-    if constexpr (WM == 2) {
-      if (nact == 2) {
-        const int cbase = (wrow0 >> 6) * 32;            // channel of packed tile pair
-        float* yb = a.y + (int64_t)b * a.y_bstride;
-        const float* gc = a.gate_cond ? a.gate_cond + (int64_t)b * a.gate_cond_bstride : nullptr;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * hl;
-          if (c >= a.gate_half) continue;
-          float bt = a.bias ? a.bias[c] : 0.f;
-          float bs = a.bias ? a.bias[a.gate_half + c] : 0.f;
-          if (gc) { bt += gc[c]; bs += gc[a.gate_half + c]; }
+          const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+          const float bias = __shfl(rowc, k);              // every lane takes part (no early exit above)
+          const int row = wrow0 + k;
+          if (i >= nact || row >= a.M) continue;
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
             const int t = t0 + wn * 32 * WN + j * 32 + l31;
-            if (t < T) {
-              const float vt = tanhf(acc[0][j][r] + bt);
-              const float vs = sigmoidf_(acc[1][j][r] + bs);
-              yb[(int64_t)c * T + t] = vt * vs;
+            if (t >= T) continue;
+            float v = acc[i][j][r] + bias;
+            const float mask = t < len_out ? 1.f : 0.f;
+            const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
+            if constexpr (EPI == EPI_STORE) {
+              if (a.relu) v = fmaxf(v, 0.f);
+              if (a.out_lens) v *= mask;
+              a.y[o] = v;
+            } else if constexpr (EPI == EPI_RESID) {
+              a.y[o] = v;
+            } else if constexpr (EPI == EPI_RESID_ACC) {
+              a.y[o] = v * a.out_scale;
+            } else if constexpr (EPI == EPI_RES_SKIP) {
+              if (row < a.split) a.y[o] = v * mask;
+              else a.skip[((int64_t)b * (a.M - a.split) + (row - a.split)) * T + t] = v;
+            } else if constexpr (EPI == EPI_COUPLE) {
+              a.y[o] = a.couple_sign * v * mask;
             }
           }
         }
       }
     }
-    return;
   }
-
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    if (i >= nact) break;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-      if (row >= a.M) continue;
-      const float bias = a.bias ? a.bias[row] : 0.f;
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int t = t0 + wn * 32 * WN + j * 32 + l31;
-        if (t >= T) continue;
-        float v = acc[i][j][r] + bias;
-        const float mask = t < len_out ? 1.f : 0.f;
-        switch (a.epi) {
-          case EPI_STORE: {
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.out_lens) v *= mask;
-            a.y[(int64_t)b * a.y_bstride + (int64_t)row * T + t] = v;
-          } break;
-          case EPI_RESID: {
-            float res = a.res[(int64_t)b * a.res_bstride + (int64_t)row * T + t];
-            if (a.res_chan_add) res += a.res_chan_add[b * a.M + row];
-            a.y[(int64_t)b * a.y_bstride + (int64_t)row * T + t] = v + res;
-          } break;
-          case EPI_RESID_ACC: {
-            float res = a.res[(int64_t)b * a.res_bstride + (int64_t)row * T + t];
-            if (a.res_chan_add) res += a.res_chan_add[b * a.M + row];
-            const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
-            float s = v + res;
-            if (a.accum_in) s = a.accum_in[o] + s;
-            a.y[o] = s * a.out_scale;
-          } break;
-          case EPI_RES_SKIP: {
-            if (row < a.split) {
-              const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
-              a.y[o] = (a.y[o] + v) * mask;
-            } else {
-              const int64_t o = ((int64_t)b * (a.M - a.split) + (row - a.split)) * T + t;
-              a.skip[o] = a.skip_accum ? a.skip[o] + v : v;
-            }
-          } break;
-          case EPI_COUPLE: {
-            const int64_t o = (int64_t)b * a.y_bstride + (int64_t)row * T + t;
-            a.y[o] = (a.y[o] + a.couple_sign * v * mask) * mask;
-          } break;
-          default: break;
-        }
-      }
-    }
-  }
+#undef MBV_ISSUE_NEXT
+#undef MBV_SETUP_TILE
+#undef MBV_ISSUE
+#undef MBV_COMMIT
 }
 
-template <int WM, int WN, int CK, int NWN>
-static void launch_one(const ConvArgs& a, hipStream_t s) {
+template <int WM, int WN, int CK, int NWN, int EPI>
+static void launch_epi(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = 64 * WM, BN = 32 * WN * NWN, G = CK / 8;
   const int XL = BN + (a.K - 1) * a.dil;
   // float4 units per buffer: input image + weight slab + one step of padding for the operand
   // prefetch overrun; two buffers for the 512-thread variant
   const size_t buf_f4 = (size_t)G * 2 * XL + (size_t)a.K * G * 2 * BM + 2 * BM;
   const size_t lds_bytes = buf_f4 * 16 * (NWN == 4 ? 2 : 1);
-  dim3 grid((a.T + BN - 1) / BN, (a.M + BM - 1) / BM, a.B);
+  const int tiles_x = (a.T + BN - 1) / BN, tiles_y = (a.M + BM - 1) / BM;
+  const long total = (long)tiles_x * tiles_y * a.B;
+  // persistent tiles: at most the workgroups that are resident at once (1 per CU for the
+  // 512-thread shape, 2 for the 256-thread one: both are register-limited to 2 waves / SIMD)
+  static const int persist = [] { const char* e = getenv("MBV_CONV_PERSIST"); return e ? atoi(e) : 1; }();
+  const long slots = 256L * (NWN == 4 ? 1 : 2);
+  const int grid = (int)((persist && total > slots) ? slots : total);
   ConvArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
   a2.debug = dbg;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN>), grid, dim3(128 * NWN), lds_bytes, s, a2);
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,
+                     tiles_x, tiles_y, (int)total);
+}
+
+// The epilogue is a compile-time parameter: with a run-time switch inside the unrolled
+// (i, r, j) nest every kernel carried all six epilogues (21 k instructions after the last MFMA,
+// SGPRs spilled to VGPR lanes) and a k=3 conv spent a quarter of its time walking that code.
+template <int WM, int WN, int CK, int NWN>
+static void launch_one(const ConvArgs& a, hipStream_t s) {
+  switch (a.epi) {
+    case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE>(a, s); break;
+    case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID>(a, s); break;
+    case EPI_RESID_ACC: launch_epi<WM, WN, CK, NWN, EPI_RESID_ACC>(a, s); break;
+    case EPI_RES_SKIP: launch_epi<WM, WN, CK, NWN, EPI_RES_SKIP>(a, s); break;
+    case EPI_COUPLE: launch_epi<WM, WN, CK, NWN, EPI_COUPLE>(a, s); break;
+    case EPI_GATE:
+      if constexpr (WM == 2) { launch_epi<WM, WN, CK, NWN, EPI_GATE>(a, s); break; }
+    default:
+      fprintf(stderr, "mbv: conv1d epilogue %d not built for this tile shape\n", a.epi);
+      abort();
+  }
 }
 
 bool conv1d_supported(int K, int dil) {
