@@ -4,7 +4,9 @@ The key names and shapes are the checkpoint contract of the reference
 (`models.py:573-655` builds the modules; old-style ``weight_norm`` gives the
 ``*.weight_g`` / ``*.weight_v`` pairs).  Only the modules
 inference entry points touch are listed (`infer`, `dec`, `voice_conversion`): the
-discriminators and the SDP are training-only / unused and have no entry.
+discriminators are training-only and have no entry.  With ``use_sdp`` the
+``dp.*`` block is the StochasticDurationPredictor's (`models.py:20-52`), including its
+training-only ``post_*`` half, so that a reference checkpoint loads strictly.
 """
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -23,6 +25,10 @@ FLOW_WN_LAYERS = 4       # models.py:647
 FLOW_N = 4               # models.py:191
 ENC_Q_LAYERS = 16        # models.py:646
 PQMF_TAPS = 62           # pqmf.py:53
+SDP_KERNEL = 3           # models.py:650 (StochasticDurationPredictor(hidden, 192, 3, 0.5, 4))
+SDP_FLOWS = 4            # models.py:650
+SDP_DDS_LAYERS = 3       # models.py:33,47
+SDP_BINS = 10            # modules.py:357
 
 
 @dataclass
@@ -48,6 +54,7 @@ class ModelConfig:
     n_speakers: int = 0
     gin_channels: int = 0
     decoder: int = DEC_MB
+    use_sdp: bool = False            # dp = StochasticDurationPredictor (models.py:649-652)
 
     # -- derived -----------------------------------------------------------
     @property
@@ -111,9 +118,6 @@ def config_from_ctor(n_vocab, spec_channels, segment_size, inter_channels, hidde
                      ms_istft_vits=False, mb_istft_vits=False, subbands=False,
                      istft_vits=False, **kwargs) -> ModelConfig:
     """Same positional/keyword surface as `models.py:573-599`."""
-    if use_sdp:
-        raise ValueError("use_sdp=True (StochasticDurationPredictor) is outside the infer hot "
-                         "path built here; every reference config sets use_sdp:false")
     if mb_istft_vits:
         dec = DEC_MB
     elif ms_istft_vits:
@@ -133,9 +137,51 @@ def config_from_ctor(n_vocab, spec_channels, segment_size, inter_channels, hidde
         upsample_kernel_sizes=[int(k) for k in upsample_kernel_sizes],
         gen_istft_n_fft=int(gen_istft_n_fft), gen_istft_hop_size=int(gen_istft_hop_size),
         subbands=1 if dec == DEC_SB else (int(subbands) if subbands else 4), n_speakers=int(n_speakers),
-        gin_channels=int(gin_channels), decoder=dec)
+        gin_channels=int(gin_channels), decoder=dec, use_sdp=bool(use_sdp))
     cfg.validate()
     return cfg
+
+
+def _sdp_shapes(s, C, gin):
+    """StochasticDurationPredictor (models.py:20-52; filter_channels := in_channels, :23).
+    Registration order of the reference: flows, post_pre, post_proj, post_convs, post_flows,
+    pre, proj, convs, cond."""
+    def dds(p):                                      # modules.py:74-96
+        for grp, shape in (("convs_sep", (C, 1, SDP_KERNEL)), ("convs_1x1", (C, C, 1))):
+            for i in range(SDP_DDS_LAYERS):
+                s[p + "%s.%d.weight" % (grp, i)] = shape
+                s[p + "%s.%d.bias" % (grp, i)] = (C,)
+        for grp in ("norms_1", "norms_2"):
+            for i in range(SDP_DDS_LAYERS):
+                s[p + "%s.%d.gamma" % (grp, i)] = (C,)
+                s[p + "%s.%d.beta" % (grp, i)] = (C,)
+
+    def flows(p):                                    # ElementwiseAffine(2) + 4 x (ConvFlow, Flip)
+        s[p + "0.m"] = (2, 1)
+        s[p + "0.logs"] = (2, 1)
+        for f in range(SDP_FLOWS):
+            q = p + "%d." % (2 * f + 1)
+            s[q + "pre.weight"] = (C, 1, 1)
+            s[q + "pre.bias"] = (C,)
+            dds(q + "convs.")
+            s[q + "proj.weight"] = (3 * SDP_BINS - 1, C, 1)
+            s[q + "proj.bias"] = (3 * SDP_BINS - 1,)
+
+    flows("dp.flows.")
+    s["dp.post_pre.weight"] = (C, 1, 1)
+    s["dp.post_pre.bias"] = (C,)
+    s["dp.post_proj.weight"] = (C, C, 1)
+    s["dp.post_proj.bias"] = (C,)
+    dds("dp.post_convs.")
+    flows("dp.post_flows.")
+    s["dp.pre.weight"] = (C, C, 1)
+    s["dp.pre.bias"] = (C,)
+    s["dp.proj.weight"] = (C, C, 1)
+    s["dp.proj.bias"] = (C,)
+    dds("dp.convs.")
+    if gin:
+        s["dp.cond.weight"] = (C, gin, 1)
+        s["dp.cond.bias"] = (C,)
 
 
 def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -240,20 +286,23 @@ def param_shapes(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             s[p + "enc.cond_layer.weight_v"] = (2 * H * FLOW_WN_LAYERS, gin, 1)
         s[p + "post.weight"] = (I // 2, H, 1)
         s[p + "post.bias"] = (I // 2,)
-    # --- dp (models.py:103-137) -------------------------------------------
-    s["dp.conv_1.weight"] = (DP_FILTER, H, DP_KERNEL)
-    s["dp.conv_1.bias"] = (DP_FILTER,)
-    s["dp.norm_1.gamma"] = (DP_FILTER,)
-    s["dp.norm_1.beta"] = (DP_FILTER,)
-    s["dp.conv_2.weight"] = (DP_FILTER, DP_FILTER, DP_KERNEL)
-    s["dp.conv_2.bias"] = (DP_FILTER,)
-    s["dp.norm_2.gamma"] = (DP_FILTER,)
-    s["dp.norm_2.beta"] = (DP_FILTER,)
-    s["dp.proj.weight"] = (1, DP_FILTER, 1)
-    s["dp.proj.bias"] = (1,)
-    if gin:
-        s["dp.cond.weight"] = (H, gin, 1)
-        s["dp.cond.bias"] = (H,)
+    if cfg.use_sdp:
+        _sdp_shapes(s, H, gin)
+    else:
+        # --- dp (models.py:103-137) ---------------------------------------
+        s["dp.conv_1.weight"] = (DP_FILTER, H, DP_KERNEL)
+        s["dp.conv_1.bias"] = (DP_FILTER,)
+        s["dp.norm_1.gamma"] = (DP_FILTER,)
+        s["dp.norm_1.beta"] = (DP_FILTER,)
+        s["dp.conv_2.weight"] = (DP_FILTER, DP_FILTER, DP_KERNEL)
+        s["dp.conv_2.bias"] = (DP_FILTER,)
+        s["dp.norm_2.gamma"] = (DP_FILTER,)
+        s["dp.norm_2.beta"] = (DP_FILTER,)
+        s["dp.proj.weight"] = (1, DP_FILTER, 1)
+        s["dp.proj.bias"] = (1,)
+        if gin:
+            s["dp.cond.weight"] = (H, gin, 1)
+            s["dp.cond.bias"] = (H,)
     if cfg.has_speaker:
         s["emb_g.weight"] = (cfg.n_speakers, cfg.gin_channels)
     return s

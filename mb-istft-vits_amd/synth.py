@@ -10,7 +10,9 @@ Design notes (what a *usable* random checkpoint needs):
   * `flow.*.post` is zero-initialised in the reference (`modules.py:331-332`)
     which would make the flows the identity -> drawn non-zero here.
   * `dp.proj.bias = log 2.5` gives ~3 z-frames per token, i.e. LJSpeech-like
-    utterance lengths (T_text=200 -> T' ~ 550-650).
+    utterance lengths (T_text=200 -> T' ~ 550-650); with `use_sdp` the same comes from
+    `dp.flows.0.m`, and the zero-initialised `dp.flows.*.proj` (`modules.py:371-372`) are drawn
+    non-zero so the splines are not the identity.
   * `weight_g` is ||v|| times a per-channel gain in [0.8, 1.2] so that the
     weight-norm fold w = g * v / ||v|| is actually exercised.
 """
@@ -45,7 +47,7 @@ def _v_std(name: str, shape, cfg: ModelConfig) -> float:
         std *= 0.5
     if ".cond" in name:
         std *= 0.3
-    if name.startswith("dp.proj"):
+    if name.startswith("dp.proj") and not cfg.use_sdp:
         std *= 0.3
     return float(std)
 
@@ -81,8 +83,12 @@ def make_state_dict(cfg: ModelConfig, seed: int = 1234):
             sd[name] = (1.0 + _normal(name, seed, shape, 0.1)).astype(np.float32)
         elif name.endswith(".beta"):
             sd[name] = _normal(name, seed, shape, 0.1)
-        elif name == "dp.proj.bias":
+        elif name == "dp.proj.bias" and not cfg.use_sdp:
             sd[name] = np.full(shape, np.log(2.5), np.float32)
+        elif name.endswith("flows.0.m"):             # SDP: logw = (z - m) exp(-logs): ~3 frames / token
+            sd[name] = np.asarray([[-0.9], [0.1]], np.float32)[:shape[0]]
+        elif name.endswith("flows.0.logs"):
+            sd[name] = _normal(name, seed, shape, 0.1)
         elif name.endswith(".bias"):
             sd[name] = _normal(name, seed, shape, 0.05)
         elif name.endswith(".weight"):

@@ -161,6 +161,111 @@ def duration_predictor(W, cfg, x, x_mask, g=None):
     return F.conv1d(h * x_mask, W.w("dp.proj"), W.b("dp.proj")) * x_mask
 
 
+# --------------------------------------------------------------------------
+# StochasticDurationPredictor, reverse direction (use_sdp checkpoints)
+# --------------------------------------------------------------------------
+SDP_BINS = 10                # modules.py:357 (num_bins)
+SDP_TAIL = 5.0               # modules.py:357 (tail_bound)
+SDP_DDS_LAYERS = 3           # models.py:33,47 (n_layers of every DDSConv in the SDP)
+SDP_MIN = 1e-3               # transforms.py:7-9 (min bin width / height / derivative)
+
+
+def dds_conv(W, prefix, x, x_mask, g=None):
+    """modules.py:98-111: per layer depth-wise conv (k, dilation k**i) -> LN -> GELU -> 1x1 ->
+    LN -> GELU -> residual; mask on the way in and out."""
+    if g is not None:
+        x = x + g
+    C = x.shape[1]
+    for i in range(SDP_DDS_LAYERS):
+        w = W[prefix + ".convs_sep.%d.weight" % i]
+        k = w.shape[-1]
+        d = k ** i
+        y = F.conv1d(x * x_mask, w, W[prefix + ".convs_sep.%d.bias" % i], padding=(k * d - d) // 2,
+                     dilation=d, groups=C)
+        y = channel_layer_norm(y, W[prefix + ".norms_1.%d.gamma" % i], W[prefix + ".norms_1.%d.beta" % i])
+        y = F.gelu(y)
+        y = F.conv1d(y, W[prefix + ".convs_1x1.%d.weight" % i], W[prefix + ".convs_1x1.%d.bias" % i])
+        y = channel_layer_norm(y, W[prefix + ".norms_2.%d.gamma" % i], W[prefix + ".norms_2.%d.beta" % i])
+        y = F.gelu(y)
+        x = x + y
+    return x * x_mask
+
+
+def rq_spline_inverse(y, uw, uh, ud):
+    """transforms.py:55-98 (linear tails) + 100-170 (inverse branch), element-wise.
+    y [...], uw/uh [..., 10], ud [..., 9].  Outside [-5, 5] the transform is the identity."""
+    nb = uw.shape[-1]
+    inside = (y >= -SDP_TAIL) & (y <= SDP_TAIL)
+    const = float(np.log(np.exp(1 - SDP_MIN) - 1))              # transforms.py:74
+    ud = F.pad(ud, (1, 1))
+    ud[..., 0] = const
+    ud[..., -1] = const
+
+    def knots(u):                                               # transforms.py:118-125 / 129-136
+        p = F.softmax(u, dim=-1)
+        p = SDP_MIN + (1 - SDP_MIN * nb) * p
+        c = F.pad(torch.cumsum(p, dim=-1), (1, 0))
+        c = 2 * SDP_TAIL * c - SDP_TAIL
+        c[..., 0] = -SDP_TAIL
+        c[..., -1] = SDP_TAIL
+        return c, c[..., 1:] - c[..., :-1]
+
+    cw, widths = knots(uw)
+    ch, heights = knots(uh)
+    deriv = SDP_MIN + F.softplus(ud)
+    yc = torch.where(inside, y, torch.zeros_like(y))
+    edges = ch.clone()
+    edges[..., -1] += 1e-6                                      # transforms.py:46-51
+    idx = (torch.sum(yc[..., None] >= edges, dim=-1) - 1).clamp(0, nb - 1)[..., None]
+    take = lambda t: t.gather(-1, idx)[..., 0]
+    in_cw, in_w, in_ch, in_h = take(cw), take(widths), take(ch), take(heights)
+    in_delta = take(heights / widths)
+    d0, d1 = take(deriv), take(deriv[..., 1:])
+    t = yc - in_ch
+    s2 = d0 + d1 - 2 * in_delta
+    a = t * s2 + in_h * (in_delta - d0)
+    b = in_h * d0 - t * s2
+    c = -in_delta * t
+    root = (2 * c) / (-b - torch.sqrt(b * b - 4 * a * c))
+    return torch.where(inside, root * in_w + in_cw, y)
+
+
+def stochastic_duration_predictor(W, cfg, x, x_mask, g=None, noise=None, noise_scale_w=1.0, taps=None):
+    """models.py:53-60, 89-100 (reverse=True): conditioning trunk, then the flow list
+    [Flip, ConvFlow_3, Flip, ConvFlow_2, Flip, ConvFlow_1, Flip, ElementwiseAffine] applied to
+    z = noise * noise_scale_w ([B, 2, T]); logw = channel 0.  `noise` replaces torch.randn
+    (models.py:94); None == zeros."""
+    C = x.shape[1]
+    h = F.conv1d(x, W["dp.pre.weight"], W["dp.pre.bias"])
+    if g is not None:
+        h = h + F.conv1d(g, W["dp.cond.weight"], W["dp.cond.bias"])
+    h = dds_conv(W, "dp.convs", h, x_mask)
+    cond = F.conv1d(h, W["dp.proj.weight"], W["dp.proj.bias"])
+    if taps is not None:
+        taps["sdp_proj"] = cond
+    cond = cond * x_mask
+    B, _, T = x.shape
+    z = torch.zeros(B, 2, T) if noise is None else torch.as_tensor(noise).float() * noise_scale_w
+    for f in (7, 5, 3):                                         # dp.flows.1 is dropped (models.py:93)
+        z = torch.flip(z, [1])                                  # modules.py:282
+        p = "dp.flows.%d" % f                                   # ConvFlow, modules.py:377-400
+        x0, x1 = z[:, :1], z[:, 1:]
+        hh = F.conv1d(x0, W[p + ".pre.weight"], W[p + ".pre.bias"])
+        hh = dds_conv(W, p + ".convs", hh, x_mask, g=cond)
+        hh = F.conv1d(hh, W[p + ".proj.weight"], W[p + ".proj.bias"]) * x_mask
+        hh = hh.reshape(B, 1, -1, T).permute(0, 1, 3, 2)         # [B, 1, T, 29]
+        uw = hh[..., :SDP_BINS] / math.sqrt(C)
+        uh = hh[..., SDP_BINS:2 * SDP_BINS] / math.sqrt(C)
+        ud = hh[..., 2 * SDP_BINS:]
+        x1 = rq_spline_inverse(x1, uw, uh, ud)
+        z = torch.cat([x0, x1], 1) * x_mask
+        if taps is not None:
+            taps["sdp_flow_%d" % f] = z
+    z = torch.flip(z, [1])
+    z = (z - W["dp.flows.0.m"]) * torch.exp(-W["dp.flows.0.logs"]) * x_mask   # modules.py:304
+    return z[:, :1]
+
+
 def length_regulate(logw, x_mask, m_p, logs_p, length_scale=1.0, t_frames=None):
     """models.py:717-725 + commons.generate_path (commons.py:128-143).
     The attn-matmul is restated as what it is: token t repeated w_ceil[t] times."""
@@ -439,9 +544,10 @@ def decode(sd, cfg, z, g=None, taps=None):
 # the whole path (models.py:697-737)
 # --------------------------------------------------------------------------
 def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_scale=1.0,
-          max_len=None, want_taps=False, t_frames=None):
+          max_len=None, want_taps=False, t_frames=None, noise_w=None, noise_scale_w=1.0):
     """Returns a dict with every stage boundary of `SynthesizerTrn.infer`.
-    `noise` replaces torch.randn_like(m_p) (models.py:729); None == zeros."""
+    `noise` replaces torch.randn_like(m_p) (models.py:729); None == zeros.  `noise_w` [B, 2, T]
+    replaces the SDP's torch.randn (models.py:94) when cfg.use_sdp."""
     W = sd if isinstance(sd, Weights) else Weights(sd)
     ids = torch.as_tensor(ids).long()
     lengths = torch.as_tensor(lengths).long()
@@ -451,7 +557,10 @@ def infer(sd, cfg, ids, lengths, sid=None, noise=None, noise_scale=0.0, length_s
         g = None
         if cfg.n_speakers > 0:
             g = W["emb_g.weight"][torch.as_tensor(sid).long()].unsqueeze(-1)
-        logw = duration_predictor(W, cfg, x, x_mask, g)
+        if getattr(cfg, "use_sdp", False):                       # models.py:711-714
+            logw = stochastic_duration_predictor(W, cfg, x, x_mask, g, noise_w, noise_scale_w, taps)
+        else:
+            logw = duration_predictor(W, cfg, x, x_mask, g)
         w_ceil, y_lengths, y_mask, attn, m_p, logs_p = length_regulate(
             logw, x_mask, m_t, logs_t, length_scale, t_frames)
         if noise is None or noise_scale == 0:

@@ -55,7 +55,7 @@ def build_reference_model(models, utils, cfg_name, n_vocab, overrides=None):
     return hps, net
 
 
-def capture(net, x, x_lengths, sid):
+def capture(net, x, x_lengths, sid, noise_seed=None):
     import torch
     taps = {}
     hooks = []
@@ -70,6 +70,10 @@ def capture(net, x, x_lengths, sid):
         lambda m, i, o: taps.update(x_enc=o[0].clone(), m_text=o[1].clone(),
                                     logs_text=o[2].clone(), x_mask=o[3].clone())))
     hooks.append(net.dp.register_forward_hook(grab("logw")))
+    if getattr(net, "use_sdp", False):              # models.py:89-100: conditioning + reversed flows
+        hooks.append(net.dp.proj.register_forward_hook(grab("sdp_proj")))
+        for f in (7, 5, 3):
+            hooks.append(net.dp.flows[f].register_forward_hook(grab("sdp_flow_%d" % f)))
     for f in range(4):
         hooks.append(net.flow.flows[2 * f].register_forward_hook(grab("flow_after_%d" % f)))
     hooks.append(net.dec.conv_pre.register_forward_hook(grab("dec_conv_pre")))
@@ -80,8 +84,14 @@ def capture(net, x, x_lengths, sid):
     post = net.dec.subband_conv_post if hasattr(net.dec, "subband_conv_post") else net.dec.conv_post
     hooks.append(post.register_forward_hook(grab("x_post")))
     with torch.no_grad():
+        if noise_seed is not None:
+            # the SDP draws torch.randn(B, 2, T) on the default CPU generator (models.py:94), the
+            # first draw of infer: re-seeding reproduces it as data for the fixture
+            torch.manual_seed(noise_seed)
+            taps["noise_w"] = torch.randn(x.size(0), 2, x.size(1))
+            torch.manual_seed(noise_seed)
         o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer(
-            x, x_lengths, sid=sid, noise_scale=0, length_scale=1)
+            x, x_lengths, sid=sid, noise_scale=0, length_scale=1, noise_scale_w=0.8)
     for h in hooks:
         h.remove()
     for i in range(2):
@@ -122,6 +132,9 @@ CASES = [
     ("sb_mini_b2", "ljs_mini_istft_vits", 59, 2, 12, [12, 7], 1234),
     ("rb2_mini_b2", "ljs_mini_mb_istft_vits", 59, 2, 16, [16, 11], 1234,
      {"resblock": "2", "resblock_dilation_sizes": [[1, 3], [1, 3], [1, 3]]}),
+    # StochasticDurationPredictor, reverse (no reference config sets use_sdp)
+    ("sdp_mini_b2", "ljs_mini_mb_istft_vits", 59, 2, 18, [18, 11], 1234, {"use_sdp": True}),
+    ("sdp_uudb_b2", "uudb_ms_istft_vits_ms", 59, 2, 14, [9, 14], 1234, {"use_sdp": True}),
 ]
 
 
@@ -197,7 +210,8 @@ def main():
                 x[b, xl[b]:] = 0
             sid = rs.randint(0, cfg.n_speakers, size=(B,)).astype(np.int64) if cfg.has_speaker else None
             taps = capture(net, torch.from_numpy(x), torch.from_numpy(xl),
-                           torch.from_numpy(sid) if sid is not None else None)
+                           torch.from_numpy(sid) if sid is not None else None,
+                           noise_seed=(4321 + seed) if cfg.use_sdp else None)
             w = (torch.exp(taps["logw"]) * taps["x_mask"]).numpy()
             w = w[taps["x_mask"].numpy() > 0]
             margin = float(np.min(np.abs(w - np.round(w))))

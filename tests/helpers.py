@@ -15,9 +15,14 @@ FIXTURES = {
     "mb_short": "ljs_mb_istft_vits",
     "sb_mini_b2": "ljs_mini_istft_vits",
     "rb2_mini_b2": "ljs_mini_mb_istft_vits",
+    "sdp_mini_b2": "ljs_mini_mb_istft_vits",
+    "sdp_uudb_b2": "uudb_ms_istft_vits_ms",
 }
 # model-block overrides a fixture was generated with (no reference config ships resblock "2")
-OVERRIDES = {"rb2_mini_b2": {"resblock": "2", "resblock_dilation_sizes": [[1, 3], [1, 3], [1, 3]]}}
+OVERRIDES = {"rb2_mini_b2": {"resblock": "2", "resblock_dilation_sizes": [[1, 3], [1, 3], [1, 3]]},
+             # StochasticDurationPredictor: no reference config sets use_sdp
+             "sdp_mini_b2": {"use_sdp": True}, "sdp_uudb_b2": {"use_sdp": True}}
+SDP_NOISE_SCALE_W = 0.8      # noise_scale_w the sdp_* fixtures were captured with
 
 
 def load_fixture(name):

@@ -7,10 +7,10 @@ import pytest
 import torch
 
 from oracle import ref_infer as R
-from helpers import FIXTURES, OVERRIDES, load_fixture, config_for, thin, rms
+from helpers import FIXTURES, OVERRIDES, SDP_NOISE_SCALE_W, load_fixture, config_for, thin, rms
 from mb_istft_vits_amd import synth
 
-STAGES = ["x_enc", "m_text", "logs_text", "logw", "attn", "m_p", "logs_p", "z_p",
+STAGES = ["x_enc", "m_text", "logs_text", "sdp_proj", "sdp_flow_7", "sdp_flow_5", "sdp_flow_3", "logw", "attn", "m_p", "logs_p", "z_p",
           "flow_after_3", "flow_after_2", "flow_after_1", "flow_after_0", "z",
           "dec_conv_pre", "dec_up_0", "dec_res_0", "dec_up_1", "dec_res_1", "x_post",
           "spec", "phase", "o_mb", "o"]
@@ -22,12 +22,13 @@ def test_infer_matches_reference(fixture):
     _, cfg = config_for(FIXTURES[fixture], int(gold["n_vocab"]), OVERRIDES.get(fixture))
     sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
     torch.set_num_threads(4)
-    out = R.infer(sd, cfg, gold["x"], gold["x_lengths"], gold.get("sid"), want_taps=True)
+    out = R.infer(sd, cfg, gold["x"], gold["x_lengths"], gold.get("sid"), want_taps=True,
+                  noise_w=gold.get("noise_w"), noise_scale_w=SDP_NOISE_SCALE_W)
     assert np.array_equal(out["y_lengths"].numpy(), gold["y_mask"].sum((1, 2)).astype(np.int64))
     assert np.array_equal(thin("attn", out["attn"]).numpy(), gold["attn"])          # durations exact
     for name in STAGES:
         if name not in gold:                      # o_mb: iSTFT_Generator returns None (models.py:300)
-            assert name == "o_mb" and name not in out
+            assert (name == "o_mb" or name.startswith("sdp_")) and name not in out
             continue
         got = thin(name, out[name]).numpy()
         ref = gold[name]
