@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MBV_ABI_VERSION 1
+#define MBV_ABI_VERSION 2
 
 #define MBV_DEC_MULTIBAND   0   /* models.py:309 Multiband_iSTFT_Generator (fixed PQMF)        */
 #define MBV_DEC_MULTISTREAM 1   /* models.py:387 Multistream_iSTFT_Generator (trainable filter)*/
@@ -40,8 +40,7 @@ extern "C" {
 typedef struct mbv_model mbv_model;   /* opaque */
 
 /* Hyper-parameters: the ctor arguments of models.py:573-599 that shape the
- * infer path (p_dropout, segment_size, spec_channels, use_sdp, n_layers_q …
- * do not).  `struct_bytes` must be sizeof(mbv_config). */
+ * infer path (p_dropout, segment_size, n_layers_q … do not).  `struct_bytes` must be sizeof(mbv_config). */
 typedef struct mbv_config {
   int32_t struct_bytes;
   int32_t n_vocab;
@@ -60,6 +59,7 @@ typedef struct mbv_config {
   int32_t gin_channels;              /* 0 or 256 */
   int32_t decoder;                   /* MBV_DEC_* */
   int32_t device;                    /* HIP device ordinal */
+  int32_t use_sdp;                   /* 1: dp is the StochasticDurationPredictor (models.py:649-650) */
 } mbv_config;
 
 /* Output bundle of phase B / decode.  Any pointer may be NULL to skip
@@ -91,8 +91,9 @@ const char *mbv_last_error(const mbv_model *m);
  * replaces nn.Module.load_state_dict as used by utils.load_checkpoint
  * (utils.py:22-47).  `name` is the reference state-dict key
  * ("dec.ups.0.weight_v", …); `data` is a HOST pointer to fp32 values of
- * `shape[0..ndim)`.  Keys the inference entry points never read (discriminators, SDP) are
- * rejected; enc_q.* is accepted (voice conversion).
+ * `shape[0..ndim)`.  Keys no module of models.SynthesizerTrn owns (discriminators, optimizer
+ * state) are rejected; enc_q.* (voice conversion) and, with use_sdp, the SDP's training-only
+ * dp.post_* half are accepted so that a reference checkpoint loads strictly.
  * mbv_finalize_weights folds weight-norm (w = g v/||v||),
  * packs every conv for the kernels, uploads once, and may be called again
  * after further mbv_load_weight calls.  It synchronises `stream`. */
@@ -111,10 +112,14 @@ int mbv_missing_weights(mbv_model *m, char *buf, size_t cap);
  *   y_lengths_out int64 [B] device     frames per utterance (clamped >= 1); -1 marks an utterance
  *                                      with a token id, length or speaker id out of range (the
  *                                      reference's nn.Embedding raises IndexError there)
+ *   noise_w  fp32 [B, 2, T]  device     use_sdp only: the standard-normal draws of models.py:94
+ *                                      (NULL == zeros); scaled by noise_scale_w inside.  Ignored
+ *                                      by the deterministic DurationPredictor.
  * The caller reads max(y_lengths) back (the one host sync of the path,
  * mirroring commons.py:123) and passes it to mbv_synthesize. */
 int mbv_encode(mbv_model *m, const int64_t *ids, const int64_t *lengths, const int64_t *sid,
-               int B, int T, float length_scale, int64_t *y_lengths_out, void *stream);
+               int B, int T, float length_scale, const float *noise_w, float noise_scale_w,
+               int64_t *y_lengths_out, void *stream);
 
 /* ---- phase B: length regulation + prior + reverse flow + decoder ----------
  * replaces models.py:720-734.

@@ -20,6 +20,9 @@ SYMBOLS = [
 ]
 
 
+ABI_VERSION = 2             # MBV_ABI_VERSION of include/mbistft_vits.h
+
+
 class MbvConfig(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_int32), ("n_vocab", C.c_int32), ("inter_channels", C.c_int32),
@@ -29,7 +32,7 @@ class MbvConfig(C.Structure):
         ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilations", (C.c_int32 * 3) * 3),
         ("resblock_type", C.c_int32),
         ("n_speakers", C.c_int32), ("gin_channels", C.c_int32), ("decoder", C.c_int32),
-        ("device", C.c_int32),
+        ("device", C.c_int32), ("use_sdp", C.c_int32),
     ]
 
 
@@ -73,7 +76,7 @@ def lib():
     L.mbv_load_weight.argtypes = [vp, C.c_char_p, vp, i64p, i32]
     L.mbv_finalize_weights.argtypes = [vp, vp]
     L.mbv_missing_weights.argtypes = [vp, C.c_char_p, C.c_size_t]
-    L.mbv_encode.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp, vp]
+    L.mbv_encode.argtypes = [vp, vp, vp, vp, i32, i32, C.c_float, vp, C.c_float, vp, vp]
     L.mbv_synthesize.argtypes = [vp, i32, vp, C.c_float, i32, C.POINTER(MbvOutputs), vp]
     L.mbv_decode.argtypes = [vp, vp, vp, i32, i32, C.POINTER(MbvOutputs), vp]
     L.mbv_speaker_embedding.argtypes = [vp, vp, i32, vp, vp]
@@ -88,7 +91,7 @@ def lib():
     L.mbv_op_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, vp]
     for s in SYMBOLS:
         getattr(L, s)          # AttributeError if the header and the library ever drift
-    if L.mbv_abi_version() != 1:
+    if L.mbv_abi_version() != ABI_VERSION:
         raise RuntimeError("libmbistft_vits.so ABI version mismatch")
     _lib = L
     return L

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 OBJS=""
-for f in conv1d ops attention istft_pqmf capi; do
+for f in conv1d ops sdp attention istft_pqmf capi; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ kernels.h -nt $f.o ] || [ ../../include/mbistft_vits.h -nt $f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $f.o &
   fi

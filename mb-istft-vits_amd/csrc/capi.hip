@@ -64,6 +64,10 @@ struct mbv_model {
   PConv enc_proj;
   PConv dp1, dp2;
   PVec dp_g1, dp_b1, dp_g2, dp_b2, dp_pw, dp_pb, dp_cw, dp_cb;
+  // StochasticDurationPredictor (models.py:20-52), reverse direction only
+  struct Dds { PVec sw[3], sb[3], g1[3], b1[3], g2[3], b2[3]; PConv c1[3]; };
+  struct SdpFlow { PVec pre_w, pre_b; Dds dds; PConv proj; };
+  struct Sdp { PConv pre, proj; Dds dds; SdpFlow flow[3]; PVec m, logs; float edge_const = 0.f; } sdp;
   struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers]; PVec cw, cb; };
   Flow flow[kNFlows];
   PConv conv_pre, conv_post;
@@ -235,16 +239,57 @@ void build_expected(mbv_model* m) {
     add_key(m, s + "post.weight", {I / 2, H, 1});
     add_key(m, s + "post.bias", {I / 2});
   }
-  add_key(m, "dp.conv_1.weight", {kDpFilter, H, 3});
-  add_key(m, "dp.conv_1.bias", {kDpFilter});
-  add_key(m, "dp.norm_1.gamma", {kDpFilter});
-  add_key(m, "dp.norm_1.beta", {kDpFilter});
-  add_key(m, "dp.conv_2.weight", {kDpFilter, kDpFilter, 3});
-  add_key(m, "dp.conv_2.bias", {kDpFilter});
-  add_key(m, "dp.norm_2.gamma", {kDpFilter});
-  add_key(m, "dp.norm_2.beta", {kDpFilter});
-  add_key(m, "dp.proj.weight", {1, kDpFilter, 1});
-  add_key(m, "dp.proj.bias", {1});
+  if (c.use_sdp) {
+    // models.py:20-52 (filter_channels := in_channels); post_* is training-only but part of the checkpoint
+    auto dds = [&](const std::string& q) {
+      for (int i = 0; i < 3; ++i) {
+        const std::string n = std::to_string(i);
+        add_key(m, q + "convs_sep." + n + ".weight", {H, 1, 3});
+        add_key(m, q + "convs_sep." + n + ".bias", {H});
+        add_key(m, q + "convs_1x1." + n + ".weight", {H, H, 1});
+        add_key(m, q + "convs_1x1." + n + ".bias", {H});
+        for (const char* g : {"norms_1.", "norms_2."}) {
+          add_key(m, q + g + n + ".gamma", {H});
+          add_key(m, q + g + n + ".beta", {H});
+        }
+      }
+    };
+    auto flows = [&](const std::string& q) {
+      add_key(m, q + "0.m", {2, 1});
+      add_key(m, q + "0.logs", {2, 1});
+      for (int f = 1; f <= 7; f += 2) {
+        const std::string r = q + std::to_string(f) + ".";
+        add_key(m, r + "pre.weight", {H, 1, 1});
+        add_key(m, r + "pre.bias", {H});
+        dds(r + "convs.");
+        add_key(m, r + "proj.weight", {29, H, 1});
+        add_key(m, r + "proj.bias", {29});
+      }
+    };
+    flows("dp.flows.");
+    add_key(m, "dp.post_pre.weight", {H, 1, 1});
+    add_key(m, "dp.post_pre.bias", {H});
+    add_key(m, "dp.post_proj.weight", {H, H, 1});
+    add_key(m, "dp.post_proj.bias", {H});
+    dds("dp.post_convs.");
+    flows("dp.post_flows.");
+    add_key(m, "dp.pre.weight", {H, H, 1});
+    add_key(m, "dp.pre.bias", {H});
+    add_key(m, "dp.proj.weight", {H, H, 1});
+    add_key(m, "dp.proj.bias", {H});
+    dds("dp.convs.");
+  } else {
+    add_key(m, "dp.conv_1.weight", {kDpFilter, H, 3});
+    add_key(m, "dp.conv_1.bias", {kDpFilter});
+    add_key(m, "dp.norm_1.gamma", {kDpFilter});
+    add_key(m, "dp.norm_1.beta", {kDpFilter});
+    add_key(m, "dp.conv_2.weight", {kDpFilter, kDpFilter, 3});
+    add_key(m, "dp.conv_2.bias", {kDpFilter});
+    add_key(m, "dp.norm_2.gamma", {kDpFilter});
+    add_key(m, "dp.norm_2.beta", {kDpFilter});
+    add_key(m, "dp.proj.weight", {1, kDpFilter, 1});
+    add_key(m, "dp.proj.bias", {1});
+  }
   if (gin) {
     add_key(m, "dp.cond.weight", {H, gin, 1});
     add_key(m, "dp.cond.bias", {H});
@@ -451,11 +496,39 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
     L.ffn2 = P.conv_plain(std::string(p) + "conv_2");
   }
   m->enc_proj = P.conv_plain("enc_p.proj");
-  m->dp1 = P.conv_plain("dp.conv_1");
-  m->dp2 = P.conv_plain("dp.conv_2");
-  m->dp_g1 = P.vec("dp.norm_1.gamma"); m->dp_b1 = P.vec("dp.norm_1.beta");
-  m->dp_g2 = P.vec("dp.norm_2.gamma"); m->dp_b2 = P.vec("dp.norm_2.beta");
-  m->dp_pw = P.vec("dp.proj.weight"); m->dp_pb = P.vec("dp.proj.bias");
+  if (c.use_sdp) {
+    auto dds = [&](const std::string& q) {
+      mbv_model::Dds d;
+      for (int i = 0; i < 3; ++i) {
+        const std::string n = std::to_string(i);
+        d.sw[i] = P.vec(q + "convs_sep." + n + ".weight");     // [C, 1, 3] -> [C][3]
+        d.sb[i] = P.vec(q + "convs_sep." + n + ".bias");
+        d.c1[i] = P.conv_plain(q + "convs_1x1." + n);
+        d.g1[i] = P.vec(q + "norms_1." + n + ".gamma"); d.b1[i] = P.vec(q + "norms_1." + n + ".beta");
+        d.g2[i] = P.vec(q + "norms_2." + n + ".gamma"); d.b2[i] = P.vec(q + "norms_2." + n + ".beta");
+      }
+      return d;
+    };
+    m->sdp.pre = P.conv_plain("dp.pre");
+    m->sdp.proj = P.conv_plain("dp.proj");
+    m->sdp.dds = dds("dp.convs.");
+    for (int k = 0; k < 3; ++k) {               // reverse order of use: flows 7, 5, 3 (models.py:92-93)
+      const std::string q = "dp.flows." + std::to_string(7 - 2 * k) + ".";
+      m->sdp.flow[k].pre_w = P.vec(q + "pre.weight");
+      m->sdp.flow[k].pre_b = P.vec(q + "pre.bias");
+      m->sdp.flow[k].dds = dds(q + "convs.");
+      m->sdp.flow[k].proj = P.conv_plain(q + "proj");
+    }
+    m->sdp.m = P.vec("dp.flows.0.m");
+    m->sdp.logs = P.vec("dp.flows.0.logs");
+    m->sdp.edge_const = (float)std::log(std::exp(1.0 - 1e-3) - 1.0);   // transforms.py:74
+  } else {
+    m->dp1 = P.conv_plain("dp.conv_1");
+    m->dp2 = P.conv_plain("dp.conv_2");
+    m->dp_g1 = P.vec("dp.norm_1.gamma"); m->dp_b1 = P.vec("dp.norm_1.beta");
+    m->dp_g2 = P.vec("dp.norm_2.gamma"); m->dp_b2 = P.vec("dp.norm_2.beta");
+    m->dp_pw = P.vec("dp.proj.weight"); m->dp_pb = P.vec("dp.proj.bias");
+  }
   m->dp_cw = P.vec("dp.cond.weight"); m->dp_cb = P.vec("dp.cond.bias");
   m->emb_g = P.vec("emb_g.weight");
 
@@ -950,8 +1023,25 @@ int mbv_speaker_embedding(mbv_model* m, const int64_t* sid, int B, float* out, v
   return 0;
 }
 
+namespace {
+// DDSConv (modules.py:98-111) on x [B, C, T] in place; t1, t2: scratch of the same size
+void run_dds(mbv_model* m, const mbv_model::Dds& d, float* x, float* t1, float* t2, int B, int C, int T,
+             hipStream_t s) {
+  const int64_t bs = (int64_t)C * T;
+  int dil = 1;
+  for (int i = 0; i < 3; ++i, dil *= 3) {
+    launch_dds_sep(x, m->lens32, m->W(d.sw[i].off), m->W(d.sb[i].off), m->W(d.g1[i].off),
+                   m->W(d.b1[i].off), t1, B, C, T, 3, dil, s);
+    launch_conv1d(conv_args(m, d.c1[i], t1, bs, T, t2, bs, T, B), s);
+    launch_dds_res(t2, x, m->W(d.g2[i].off), m->W(d.b2[i].off), x, B, C, T,
+                   i == 2 ? m->lens32 : nullptr, s);
+  }
+}
+}  // namespace
+
 int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const int64_t* sid, int B,
-               int T, float length_scale, int64_t* y_lengths_out, void* stream) {
+               int T, float length_scale, const float* noise_w, float noise_scale_w,
+               int64_t* y_lengths_out, void* stream) {
   if (!m) return 1;
   if (!m->finalized) return m->fail("weights not finalized (call mbv_finalize_weights)");
   if (!ids || !lengths || B <= 0 || T <= 0) return m->fail("mbv_encode: bad arguments");
@@ -962,7 +1052,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   hipStream_t s = (hipStream_t)stream;
   const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels, gin = c.gin_channels;
   const size_t BT = (size_t)B * T;
-  size_t need = (BT * (H * 5 + 3 * H + Fc + 2 * I + 2 * kDpFilter + 4) + (size_t)B * (gin + H + 12)) * 4 + 64 * 256;
+  size_t need = (BT * (H * 5 + 3 * H + Fc + 2 * I + 2 * kDpFilter + 4 + 5 * H + 32 + 2) + (size_t)B * (gin + H + 12)) * 4 + 96 * 256;
   if (ensure(m, &m->scrA, &m->scrA_bytes, need)) return 1;
   Bump sc{m->scrA, m->scrA_bytes};
   float* x = sc.take<float>(BT * H);
@@ -1026,6 +1116,40 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
       cadd = dpc;
     }
   }
+  if (c.use_sdp) {
+    // models.py:53-60: conditioning trunk; :89-100: z through [Flip, ConvFlow] x 3, Flip, affine
+    float* cond = sc.take<float>(BT * H);
+    float* hh = sc.take<float>(BT * H);
+    float* t1 = sc.take<float>(BT * H);
+    float* t2 = sc.take<float>(BT * H);
+    float* h29 = sc.take<float>(BT * 32);
+    float* zf = sc.take<float>(BT * 2);
+    launch_conv1d(conv_args(m, m->sdp.pre, x, bsH, T, hh, bsH, T, B), s);
+    if (cadd) launch_chan_add(hh, cadd, B, H, T, s);
+    run_dds(m, m->sdp.dds, hh, t1, t2, B, H, T, s);
+    {
+      ConvArgs a = conv_args(m, m->sdp.proj, hh, bsH, T, cond, bsH, T, B);
+      a.out_lens = m->lens32;
+      launch_conv1d(a, s);
+    }
+    launch_sdp_noise(noise_w, noise_scale_w, zf, (int64_t)BT * 2, s);
+    for (int k = 0; k < 3; ++k) {
+      const auto& f = m->sdp.flow[k];
+      launch_sdp_pre(zf, 1, m->W(f.pre_w.off), m->W(f.pre_b.off), cond, hh, B, H, T, s);   // x0 = z[:, 1] after the Flip
+      run_dds(m, f.dds, hh, t1, t2, B, H, T, s);
+      {
+        ConvArgs a = conv_args(m, f.proj, hh, bsH, T, h29, (int64_t)29 * T, T, B);
+        a.out_lens = m->lens32;
+        launch_conv1d(a, s);
+      }
+      launch_sdp_spline(h29, zf, m->lens32, B, H, T, m->sdp.edge_const, s);
+    }
+    launch_sdp_logw(zf, m->W(m->sdp.m.off), m->W(m->sdp.logs.off), m->lens32, h29, B, T, s);
+    launch_durations(h29, nullptr, nullptr, m->lens32, length_scale, m->logw, m->w_ceil, m->cum,
+                     m->ylen32, y_lengths_out, bad, B, 1, T, s);
+    m->stages["sdp_cond"] = {cond, (int64_t)BT * H};
+    m->stages["sdp_z"] = {zf, (int64_t)BT * 2};
+  } else {
   {
     ConvArgs a = conv_args(m, m->dp1, x, bsH, T, h1, (int64_t)kDpFilter * T, T, B);
     a.in_lens = m->lens32; a.chan_add = cadd;
@@ -1040,6 +1164,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   launch_layernorm(h1, nullptr, m->W(m->dp_g2.off), m->W(m->dp_b2.off), h2, B, kDpFilter, T, 1, nullptr, s);
   launch_durations(h2, m->W(m->dp_pw.off), m->W(m->dp_pb.off), m->lens32, length_scale, m->logw,
                    m->w_ceil, m->cum, m->ylen32, y_lengths_out, bad, B, kDpFilter, T, s);
+  }
   HIPCHK(m, hipEventRecord(m->ev[2], s));
   HIPCHK(m, hipGetLastError());
   m->B = B; m->T = T; m->encoded = true; m->ev_a = true; m->ev_b = false;

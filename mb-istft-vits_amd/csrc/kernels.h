@@ -95,6 +95,26 @@ void launch_rel_attention(const float* qkv, const float* emb_k, const float* emb
 void launch_durations(const float* h, const float* w, const float* b, const int* lens,
                       float length_scale, float* logw, float* w_ceil, int* cum, int* ylen32,
                       int64_t* ylen64, const int* bad, int B, int C, int T, hipStream_t s);
+// (w == nullptr: h is logw itself, [B, T] — the SDP path)
+
+// ---------------------------------------------------------------- StochasticDurationPredictor (sdp.hip)
+// DDSConv halves (modules.py:98-111), C <= 256
+void launch_dds_sep(const float* x, const int* lens, const float* w, const float* bias,
+                    const float* gamma, const float* beta, float* y, int B, int C, int T, int K,
+                    int dil, hipStream_t s);
+void launch_dds_res(const float* a, const float* xres, const float* gamma, const float* beta,
+                    float* y, int B, int C, int T, const int* out_lens, hipStream_t s);
+// h = pre_w * z[:, zc] + pre_b + cond                      (ConvFlow.pre + DDSConv's x + g)
+void launch_sdp_pre(const float* z, int zc, const float* pre_w, const float* pre_b, const float* cond,
+                    float* h, int B, int C, int T, hipStream_t s);
+// Flip + inverse rational-quadratic spline + mask, in place on z [B, 2, T]; h [B, 29, T]
+void launch_sdp_spline(const float* h, float* z, const int* lens, int B, int C, int T,
+                       float edge_const, hipStream_t s);
+void launch_sdp_logw(const float* z, const float* m, const float* logs, const int* lens, float* logw,
+                     int B, int T, hipStream_t s);
+void launch_sdp_noise(const float* noise, float scale, float* z, int64_t n, hipStream_t s);
+// x[b, c, t] += v[b, c]
+void launch_chan_add(float* x, const float* v, int B, int C, int T, hipStream_t s);
 // m_t / logs_t: [B, C, T] views with batch stride src_bstride (halves of the enc_p.proj output)
 void launch_expand(const float* m_t, const float* logs_t, int64_t src_bstride, const int* cum,
                    const int* ylen, const float* noise, float noise_scale, float* m_p,

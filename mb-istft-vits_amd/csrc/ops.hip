@@ -129,10 +129,14 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* h, const fl
     if (t < T) {
       float lw = 0.f, wc = 0.f;
       if (t < len) {
-        float acc = 0.f;
-        const float* hp = h + (int64_t)b * C * T + t;
-        for (int c = 0; c < C; ++c) acc = fmaf(w[c], hp[(int64_t)c * T], acc);
-        lw = acc + bias[0];
+        if (w) {
+          float acc = 0.f;
+          const float* hp = h + (int64_t)b * C * T + t;
+          for (int c = 0; c < C; ++c) acc = fmaf(w[c], hp[(int64_t)c * T], acc);
+          lw = acc + bias[0];
+        } else {
+          lw = h[(int64_t)b * T + t];            // SDP: logw computed by the flows (sdp.hip)
+        }
         wc = ceilf(expf(lw) * length_scale);
       }
       logw[(int64_t)b * T + t] = lw;

@@ -188,6 +188,7 @@ class SynthesizerTrn(nn.Module):
             c.n_speakers, c.gin_channels = cfg.n_speakers, cfg.gin_channels
             c.decoder = int(cfg.decoder)
             c.device = idx
+            c.use_sdp = int(bool(cfg.use_sdp))
             h = C.c_void_p()
             rc = L.mbv_create(C.byref(c), C.byref(h))
             if rc:
@@ -259,7 +260,7 @@ class SynthesizerTrn(nn.Module):
     # ------------------------------------------------------------------ API
     @torch.no_grad()
     def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode,
-             frames_hook=None):
+             frames_hook=None, noise_scale_w=1.):
         h = self._ensure_handle()
         L = _capi.lib()
         x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
@@ -268,8 +269,13 @@ class SynthesizerTrn(nn.Module):
         with torch.cuda.device(dev):
             stream = self._stream()
             y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
+            noise_w = None
+            if self.cfg.use_sdp:
+                # the reference draws on the default CPU generator and moves it over (models.py:94)
+                noise_w = torch.randn(B, 2, T).to(device=dev, dtype=torch.float32)
             _capi.check(h, L.mbv_encode(h, self._ptr(x), self._ptr(x_lengths), self._ptr(sid), B, T,
-                                        float(length_scale), self._ptr(y_lengths), stream),
+                                        float(length_scale), self._ptr(noise_w), float(noise_scale_w),
+                                        self._ptr(y_lengths), stream),
                         "mbv_encode")
             lo, hi = torch.aminmax(y_lengths)
             Tp = int(hi.item())                     # the one host sync (commons.py:123)
@@ -322,20 +328,23 @@ class SynthesizerTrn(nn.Module):
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
               max_len=None):
         """-> (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:737)"""
-        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True)
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
+                      noise_scale_w=noise_scale_w)
         return r[:8]
 
     def infer_z_only(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
                      max_len=None):
         """-> (attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:742-788)"""
-        r = self._run(x, x_lengths, sid, noise_scale, length_scale, None, decode=False)
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, None, decode=False,
+                      noise_scale_w=noise_scale_w)
         return r[4], r[5], r[6], r[7]
 
     def infer_with_lengths(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
-                           max_len=None):
+                           max_len=None, noise_scale_w=1.):
         """`infer` plus the per-utterance frame counts y_lengths [B] (int64) — what a batched
         caller needs to trim the padded waveforms (valid samples = 256 * y_lengths)."""
-        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True)
+        r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
+                      noise_scale_w=noise_scale_w)
         return r[:8], r[8]
 
     @torch.no_grad()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FIXTURES, OVERRIDES, load_fixture, config_for, thin, rms
+from helpers import FIXTURES, OVERRIDES, SDP_NOISE_SCALE_W, load_fixture, config_for, thin, rms
 from oracle import ref_infer as R
 
 pytestmark = pytest.mark.gpu
@@ -31,8 +31,12 @@ def test_infer_matches_reference_golden(fixture):
     x = torch.from_numpy(gold["x"]).cuda()
     xl = torch.from_numpy(gold["x_lengths"]).cuda()
     sid = torch.from_numpy(gold["sid"]).cuda() if "sid" in gold else None
+    if net.use_sdp:
+        # like the reference, the shim draws the SDP noise from torch's default CPU generator
+        # (models.py:94): the seed the fixture was captured with reproduces it
+        torch.manual_seed(4321 + int(gold["weight_seed"]))
     o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer(
-        x, xl, sid=sid, noise_scale=0, length_scale=1)
+        x, xl, sid=sid, noise_scale=0, length_scale=1, noise_scale_w=SDP_NOISE_SCALE_W)
     B, T = gold["x"].shape
     Tp = z.shape[-1]
     report = {}
@@ -44,9 +48,11 @@ def test_infer_matches_reference_golden(fixture):
               "dec_conv_pre": (B, -1, Tp), "dec_up_0": (B, -1, u * Tp), "dec_res_0": (B, -1, u * Tp),
               "dec_up_1": (B, -1, u * u * Tp), "dec_res_1": (B, -1, u * u * Tp),
               "x_post": (B, net.cfg.post_channels, u * u * Tp + 1)}
+    if net.use_sdp:                                 # z after flows 7, 5, 3 (ConvFlow.reverse outputs)
+        shapes["sdp_z"] = (B, 2, T)
     for name, shp in shapes.items():
         got = thin(name, net.read_stage(name).reshape(*shp).cpu()).numpy()
-        report[name] = _rel(got, gold[name])
+        report[name] = _rel(got, gold["sdp_flow_3" if name == "sdp_z" else name])
     outs = dict(m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, spec=spec, phase=phase, o_mb=o_mb, o=o)
     if "o_mb" not in gold:                          # iSTFT_Generator: (out, None, spec, phase)
         assert o_mb is None
@@ -103,6 +109,33 @@ def test_infer_vs_oracle_ragged_batch_with_noise_and_maxlen():
     assert o.shape == ref["o"].shape
     assert _rel(z.cpu().numpy(), ref["z"].numpy()) < 5e-5
     assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
+def test_sdp_fresh_ragged_batch_vs_oracle():
+    """StochasticDurationPredictor (use_sdp) on inputs outside the goldens: ragged batch of 5 x 60
+    tokens, full-size config, noise_scale_w 0.667 (the reference's usual inference value) and the
+    zero-noise case; durations exact, logw within 5e-5."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits", seed=1236, overrides={"use_sdp": True})
+    for nsw, seed in ((0.667, 31), (0.0, 32)):
+        for attempt in range(8):                    # redraw if a duration sits on a ceil() edge
+            x, xl, _ = synth.synthetic_batch(net.cfg, 5, 60, seed=seed + 100 * attempt, ragged=True)
+            torch.manual_seed(7 + attempt)
+            noise_w = torch.randn(5, 2, 60)
+            ref = R.infer(sd, net.cfg, x, xl, None, noise_w=noise_w, noise_scale_w=nsw, length_scale=1.0)
+            w = (torch.exp(ref["logw"]) * ref["x_mask"]).numpy()[ref["x_mask"].numpy() > 0]
+            if np.min(np.abs(w - np.round(w))) > 1e-3:
+                break
+        torch.manual_seed(7 + attempt)              # the shim draws randn(B, 2, T) first (models.py:94)
+        (o, _, _, _, attn, _, (z, _, _, _), _), ylen = net.infer_with_lengths(
+            torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda(), noise_scale=0, length_scale=1.0,
+            noise_scale_w=nsw)
+        logw = net.read_stage("logw").reshape(5, 1, 60).cpu().numpy()
+        assert _rel(logw, ref["logw"].numpy()) < 5e-5
+        assert np.array_equal(ylen.cpu().numpy(), ref["y_lengths"].numpy())
+        assert np.array_equal(attn.sum(2).cpu().numpy(), ref["attn"].sum(2).numpy())
+        assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
 
 
 def test_infer_z_only_and_errors():

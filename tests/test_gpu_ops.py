@@ -184,7 +184,7 @@ def test_c_abi_error_paths(net):
         lens = torch.tensor([4], device="cuda")
         yl = torch.zeros(1, dtype=torch.int64, device="cuda")
         assert L.mbv_encode(h, C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), None, 1, 4,
-                            C.c_float(1.0), C.c_void_p(yl.data_ptr()), None) != 0
+                            C.c_float(1.0), None, C.c_float(1.0), C.c_void_p(yl.data_ptr()), None) != 0
         assert b"finalize" in L.mbv_last_error(h)
         assert L.mbv_finalize_weights(h, None) != 0 and b"missing weight" in L.mbv_last_error(h)
         n_missing = L.mbv_missing_weights(h, None, 0)

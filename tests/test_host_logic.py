@@ -31,12 +31,12 @@ def test_header_symbols_all_exported():
     L = _capi.lib()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.mbv_abi_version() == 1
+    assert L.mbv_abi_version() == _capi.ABI_VERSION == 2
 
 
 def test_config_struct_layout_matches_header():
     # 10 scalars + 3 kernel sizes + 9 dilations + resblock_type + 4 trailing scalars, all int32
-    assert C.sizeof(_capi.MbvConfig) == 4 * (10 + 3 + 9 + 1 + 4)
+    assert C.sizeof(_capi.MbvConfig) == 4 * (10 + 3 + 9 + 1 + 4 + 1)
     assert C.sizeof(_capi.MbvOutputs) == 8 * 10
 
 
@@ -103,8 +103,9 @@ def test_hparams_behaves_like_reference():
 def test_ctor_rejects_what_is_out_of_scope():
     hps = utils.get_hparams_from_file(utils.builtin_config("ljs_mb_istft_vits"))
     kw = dict(**hps.model)
-    with pytest.raises(ValueError):
-        models.SynthesizerTrn(59, 513, 32, **{**kw, "use_sdp": True})
+    sdp = models.SynthesizerTrn(59, 513, 32, **{**kw, "use_sdp": True})   # models.py:649-650
+    assert "dp.flows.7.proj.weight" in sdp.state_dict() and "dp.post_flows.0.m" in sdp.state_dict()
+    assert "dp.conv_1.weight" not in sdp.state_dict()
     with pytest.raises(ValueError):                   # single-band family needs its own ups (8, 8)
         models.SynthesizerTrn(59, 513, 32, **{**kw, "mb_istft_vits": False, "istft_vits": True})
     with pytest.raises(ValueError):
