@@ -185,9 +185,16 @@ def main():
             ts.sort()
             return ts[1], int(r["y_lengths"].sum()) * cfg.samples_per_frame        # median of 3
 
+        # the port does not scale past a few dozen threads at this problem size (oneDNN conv over
+        # 8 utterances): time a few thread counts and report the FASTEST as the baseline
         n_all = max(1, min(os.cpu_count() or 1, 64))
-        t_all, cpu_samples = cpu_run(n_all)
-        t_8, _ = cpu_run(min(8, n_all))
+        by_threads = {}
+        cpu_samples = 0
+        for n in sorted({min(8, n_all), min(16, n_all), min(32, n_all), n_all}):
+            t_n, cpu_samples = cpu_run(n)
+            by_threads[n] = t_n
+        best = min(by_threads, key=by_threads.get)
+        t_best = by_threads[best]
         cpu_model = "unknown"
         try:
             for ln in open("/proc/cpuinfo"):
@@ -196,12 +203,13 @@ def main():
                     break
         except OSError:
             pass
-        cpu = {"value": round(cpu_samples / t_all, 1), "unit": "samples/s", "cores": n_all, "kind": "port",
+        cpu = {"value": round(cpu_samples / t_best, 1), "unit": "samples/s", "cores": best, "kind": "port",
                "sample": "first %d utterances of the batch-%d workload; oracle (PyTorch-CPU fp32 restatement "
-                         "of the reference) infer, 1 warm-up (B=2) + median of 3 timed calls" % (nb, B),
-               "rtf": round(t_all / (cpu_samples / sr), 5),
-               "value_8_threads": round(cpu_samples / t_8, 1), "cpu_model": cpu_model,
-               "torch": torch.__version__}
+                         "of the reference) infer, 1 warm-up (B=2) + median of 3 timed calls per thread "
+                         "count; value = the fastest thread count" % (nb, B),
+               "rtf": round(t_best / (cpu_samples / sr), 5),
+               "samples_per_s_by_threads": {str(n): round(cpu_samples / t, 1) for n, t in by_threads.items()},
+               "cpu_model": cpu_model, "torch": torch.__version__}
 
     if rank == 0:
         line = {
