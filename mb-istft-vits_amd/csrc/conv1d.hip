@@ -246,6 +246,40 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           if (a.res_chan_add) rowc += a.res_chan_add[b * a.M + row];
       }
     }
+    // a wave whose 32*WM x 32*WN patch lies wholly inside [M, T] takes the unguarded paths below
+    // and in the epilogue (no per-element exec masking, loads issued back to back)
+    const bool full = wrow0 + 32 * WM <= a.M && t0 + wn * 32 * WN + 32 * WN <= a.T;
+    const int64_t lane_off = (int64_t)(wrow0 + 4 * hl) * a.T + t0 + wn * 32 * WN + l31;   // element (k = 0, j = 0)
+    if ((EPI == EPI_RESID || EPI == EPI_RESID_ACC) && full) {
+      const float* pr = a.res + (int64_t)b * a.res_bstride + lane_off;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* q = pr + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j][r] = q[j * 32];
+        }
+      if (EPI == EPI_RESID_ACC && a.accum_in) {
+        // second operand through temporaries, half a patch at a time: two waits instead of one
+        // per element (a load feeding an add right away serialises the whole initialisation)
+        const float* pa = a.accum_in + (int64_t)b * a.y_bstride + lane_off;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          float tmp[16][WN];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float* q = pa + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) tmp[r][j] = q[j * 32];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j][r] += tmp[r][j];
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -273,6 +307,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           acc[i][j][r] = v0;
         }
       }
+    }
     if constexpr (DB) { MBV_ISSUE_NEXT(); }   // second chunk of this tile (its first is in LDS)
 
     for (int c = 0; c < nck; ++c, ++q) {
@@ -383,6 +418,23 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           }
         }
       }
+    } else if ((EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_RESID_ACC) && full && !a.out_lens) {
+      float* py = a.y + (int64_t)b * a.y_bstride + lane_off;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = i * 32 + (r & 3) + 8 * (r >> 2);
+          const float bias = __shfl(rowc, k0 + 4 * hl);
+          float* q = py + (int64_t)k0 * T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            float v = acc[i][j][r] + bias;
+            if constexpr (EPI == EPI_STORE) { if (a.relu) v = fmaxf(v, 0.f); }
+            if constexpr (EPI == EPI_RESID_ACC) v *= a.out_scale;
+            q[j * 32] = v;
+          }
+        }
     } else {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
