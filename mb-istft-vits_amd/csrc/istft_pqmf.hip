@@ -399,6 +399,7 @@ void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
   // the 224 x 256-thread shape (8 workgroups / CU) for A/B runs
   static const int tile = [] { const char* e = getenv("MBV_ISTFT_TILE"); return e ? atoi(e) : 480; }();
   if (tile == 224) launch_istft_pqmf_t<224, 256>(a, s);
+  else if (tile == 960) launch_istft_pqmf_t<960, 1024>(a, s);
   else launch_istft_pqmf_t<480, 512>(a, s);
 }
 

@@ -238,6 +238,26 @@ def test_shape_sweep_against_oracle(B, T, ragged):
     assert np.array_equal(attn.cpu().numpy(), ref["attn"].numpy())
 
 
+def test_zero_length_utterance_in_batch():
+    """An empty utterance (x_lengths == 0) next to real ones: the reference clamps its y_length to 1
+    (models.py:719) and every mask zeroes it out; its row must not disturb the others."""
+    from gpu_util import make_net
+    net, sd = make_net("ljs_mini_mb_istft_vits", seed=1251)
+    rs = np.random.RandomState(5)
+    x = rs.randint(1, 59, size=(3, 9)).astype(np.int64)
+    xl = np.asarray([0, 9, 4], np.int64)
+    for b in range(3):
+        x[b, xl[b]:] = 0
+    ref = R.infer(sd, net.cfg, x, xl)
+    (o, _, _, _, attn, y_mask, (z, _, _, _), _), ylen = net.infer_with_lengths(
+        torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda(), noise_scale=0, length_scale=1)
+    assert int(ylen[0]) == 1 and np.array_equal(ylen.cpu().numpy(), ref["y_lengths"].numpy())
+    assert torch.isfinite(o).all()
+    assert np.array_equal(attn.cpu().numpy(), ref["attn"].numpy())
+    assert _rel(z.cpu().numpy(), ref["z"].numpy()) < 5e-5
+    assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
 def test_full_size_batch64_properties():
     """BASELINE.json configs[1] at full size (ljs_mb, B=64, T_text=200): size-independent checks.
       * determinism: two runs are bitwise identical;
