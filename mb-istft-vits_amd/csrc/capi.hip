@@ -74,6 +74,7 @@ struct mbv_model {
   static constexpr int kEncQLayers = 16;     // models.py:646
   struct EncQ { PConv pre, proj, in[kEncQLayers], rs[kEncQLayers]; PVec cw, cb; int cin_pad = 0; } encq;
   struct Up { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, Mpad = 0; } ups[2];
+  PConv upc[2];              // stride-4 ups as 5-tap convs over the output phases (EPI_CONVT)
   struct RB { PConv c1[3], c2[3]; PVec cw, cb; } rb[6];
   PVec emb_g;
   PVec filt;                 // synthesis-bank table of the fused iSTFT+PQMF kernel (352 floats)
@@ -613,6 +614,36 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
         }
       }
     U.bias = P.vec(std::string(p) + ".bias").off;
+    if (us == 4 && U.Cout % 32 == 0 && U.Cin % 16 == 0) {
+      // The same ConvTranspose1d as ONE 5-tap conv on the conv1d kernel (EPI_CONVT):
+      //   y[co, 4m + r] = sum_ci sum_j W[ci][co][kr + 4j] x[ci, m + sh_r - j],  kr = (r + 6) % 4,
+      //   sh_r = (r + 6 - kr) / 4;  tap tau reads x[m - 2 + tau]  ->  j = sh_r + 2 - tau.
+      // Packed rows: groups of 64 = 16 channels x [phases 0,1 (32 rows) | phases 2,3 (32 rows)],
+      // row k of a half = channel k / 2, phase k % 2.  Tap 4 is zero for the first half, tap 0 for
+      // the second; the kernel skips those MFMAs.
+      const int Mp = 4 * U.Cout;
+      PConv pc;
+      pc.M = Mp; pc.Mpad = (int)align_up(Mp, 128); pc.Cin = U.Cin; pc.K = 5;
+      pc.w = P.alloc((size_t)5 * U.Cin * pc.Mpad);
+      pc.bias = P.alloc(Mp);
+      pc.has_bias = true;
+      const HostTensor& bt = P.t(std::string(p) + ".bias");
+      for (int row = 0; row < Mp; ++row) {
+        const int grp = row / 64, half = (row % 64) / 32, k = row % 32;
+        const int co = grp * 16 + k / 2, r = 2 * half + (k & 1);
+        const int kr = (r + 6) % 4, sh = (r + 6 - kr) / 4;
+        arena[pc.bias + row] = bt.data[co];
+        for (int tau = 0; tau < 5; ++tau) {
+          const int j = sh + 2 - tau;
+          for (int ci = 0; ci < U.Cin; ++ci)
+            arena[pc.w + conv_pack_index(tau, ci, row, U.Cin, pc.Mpad)] =
+                (j >= 0 && j < 4) ? w[((size_t)ci * U.Cout + co) * 16 + kr + 4 * j] : 0.f;
+        }
+      }
+      m->upc[i] = pc;
+    } else {
+      m->upc[i] = PConv{};
+    }
   }
   for (int n = 0; n < 6; ++n) {
     if (c.resblock_type == 1) {
@@ -731,7 +762,14 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
     float* t1 = sc.take<float>(n);
     float* r = sc.take<float>(n);
     xs = sc.take<float>(n);
-    {
+    static const int convt_as_conv = [] { const char* e = getenv("MBV_CONVT_AS_CONV"); return e ? atoi(e) : 1; }();
+    if (us == 4 && m->upc[i].M && convt_as_conv) {
+      ConvArgs a = conv_args(m, m->upc[i], cur, (int64_t)m->ups[i].Cin * L, L, u, (int64_t)ch * Lo, L, B);
+      a.pad_left = 2;
+      a.in_slope = kLrelu;
+      a.epi = EPI_CONVT;
+      launch_conv1d(a, s);
+    } else {
       ConvTArgs a{};
       a.x = cur; a.w = m->W(m->ups[i].w); a.bias = m->W(m->ups[i].bias); a.y = u;
       a.B = B; a.Cin = m->ups[i].Cin; a.Cout = ch; a.Mpad = m->ups[i].Mpad; a.Tin = L;

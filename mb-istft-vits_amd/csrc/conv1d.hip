@@ -333,12 +333,17 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
             _Pragma("unroll") for (int i = 0; i < WM; ++i) AV[i] = wp_[i * 32];    \
             _Pragma("unroll") for (int j = 0; j < WN; ++j) BV[j] = xp_[j * 32];    \
           }
-#define MBV_MMA(AV, BV)                                                            \
-          _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                         \
-            _Pragma("unroll") for (int i = 0; i < WM; ++i)                         \
-              _Pragma("unroll") for (int j = 0; j < WN; ++j)                       \
-                if (j < nj)                                                        \
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0);
+          /* EPI_CONVT: the i-tile whose weights are structurally zero at this tap (none: -1) */ \
+#define MBV_SKIP(ST) (EPI == EPI_CONVT ? ((ST) / G == 0 ? 1 : ((ST) / G == a.K - 1 ? 0 : -1)) : -1)
+#define MBV_MMA(AV, BV, SK)                                                        \
+          {                                                                        \
+            const int sk_ = (SK);                                                  \
+            _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                       \
+              _Pragma("unroll") for (int i = 0; i < WM; ++i)                       \
+                _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
+                  if (j < nj && i != sk_)                                          \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0); \
+          }
           // operands double-buffered one step ahead; sched_barrier keeps hipcc from sinking the
           // prefetch back behind the MFMAs
           MBV_LOAD_AB(0, a0, b0);
@@ -346,16 +351,17 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           for (; st + 1 < nsteps; st += 2) {
             MBV_LOAD_AB(st + 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            MBV_MMA(a0, b0);
+            MBV_MMA(a0, b0, MBV_SKIP(st));
             __builtin_amdgcn_sched_barrier(0);
             MBV_LOAD_AB(st + 2, a0, b0);   // the last pass reads one step past the slab (padded, unused)
             __builtin_amdgcn_sched_barrier(0);
-            MBV_MMA(a1, b1);
+            MBV_MMA(a1, b1, MBV_SKIP(st + 1));
             __builtin_amdgcn_sched_barrier(0);
           }
-          if (st < nsteps) { MBV_MMA(a0, b0); }                // odd step count
+          if (st < nsteps) { MBV_MMA(a0, b0, MBV_SKIP(st)); }  // odd step count
 #undef MBV_LOAD_AB
 #undef MBV_MMA
+#undef MBV_SKIP
         } else if (nact == 1) {                                // only reachable with WM == 2
           for (int st = 0; st < nsteps; ++st) {
             const int tap = st / G, g = st % G;
@@ -414,6 +420,27 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
                 const float vs = sigmoidf_(acc[1][j][r] + bs);
                 yb[(int64_t)c * T + t] = vt * vs;
               }
+            }
+          }
+        }
+      }
+    } else if constexpr (EPI == EPI_CONVT) {
+      if constexpr (WM == 2) {
+        // lane: column t, rows k (even) and k + 1 of both i-tiles = the 4 output phases of one channel
+        const int Tout = 4 * T;
+        float* yb = a.y + (int64_t)b * a.y_bstride;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int k = (r & 3) + 8 * (r >> 2) + 4 * hl;
+          const float bias = __shfl(rowc, k);
+          const int co = (wrow0 >> 6) * 16 + (k >> 1);
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
+            if (t < T) {
+              f32x4 o = {acc[0][j][r] + bias, acc[0][j][r + 1] + bias, acc[1][j][r] + bias,
+                         acc[1][j][r + 1] + bias};
+              *reinterpret_cast<f32x4*>(yb + (int64_t)co * Tout + 4 * (int64_t)t) = o;
             }
           }
         }
@@ -517,6 +544,10 @@ static void launch_one(const ConvArgs& a, hipStream_t s) {
     case EPI_COUPLE: launch_epi<WM, WN, CK, NWN, EPI_COUPLE>(a, s); break;
     case EPI_GATE:
       if constexpr (WM == 2) { launch_epi<WM, WN, CK, NWN, EPI_GATE>(a, s); break; }
+    case EPI_CONVT:
+      if constexpr (WM == 2 && CK == 16) {
+        if (a.epi == EPI_CONVT) { launch_epi<WM, WN, CK, NWN, EPI_CONVT>(a, s); break; }
+      }
     default:
       fprintf(stderr, "mbv: conv1d epilogue %d not built for this tile shape\n", a.epi);
       abort();
@@ -542,7 +573,7 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
-  const bool wide_m = a.M > 64 || a.epi == EPI_GATE;
+  const bool wide_m = a.M > 64 || a.epi == EPI_GATE || a.epi == EPI_CONVT;
   // Long sequences with enough blocks to fill the chip: 512-thread workgroups, 128 x 384 tile
   // (6 accumulators per wave), double-buffered LDS.  Otherwise 256-thread, 128 x 128 tile.
   static const int mode = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();

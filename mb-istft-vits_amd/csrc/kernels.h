@@ -16,6 +16,9 @@ enum ConvEpilogue : int {
   EPI_GATE = 3,      // rows come in (tanh-tile, sigmoid-tile) pairs: y[c] = tanh(.)*sigmoid(.)
   EPI_RES_SKIP = 4,  // row < split: xio = (xio + v) * mask ; else skip[row-split] (+)= v
   EPI_COUPLE = 5,    // y = (y + couple_sign * (acc + bias) * mask) * mask   (sign -1: reverse flow)
+  EPI_CONVT = 6,     // ConvTranspose1d(k16, s4, p6) as a 5-tap conv over its 4 output phases: rows come
+                     // in groups of 64 = 16 channels x (phases 0,1 | phases 2,3); tap 0 is all-zero for
+                     // the second half, tap 4 for the first (their MFMAs are skipped); y[co, 4t .. 4t+3]
 };
 
 struct ConvArgs {
