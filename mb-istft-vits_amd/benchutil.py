@@ -6,7 +6,7 @@ import torch
 from . import _capi
 
 
-def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True):
+def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True, warm=1000):
     """Average duration (ms) of the fused iSTFT+PQMF launch in waveform-only mode on a
     [B, 72, 16 Tp + 1] input, HIP events on the launch stream.  prescaled=True times the variant
     the decoder stack uses (x_post in the library's internal units, see mbistft_vits.h)."""
@@ -25,7 +25,10 @@ def istft_waveform_only_ms(net, B, Tp, iters=50, x_post=None, prescaled=True):
         rc = L.mbv_istft_pqmf(h, C.c_void_p(x_post.data_ptr()), B, Tp, None, 2 if prescaled else 0,
                               C.c_void_p(o.data_ptr()), None, None, None, sp)
         _capi.check(h, rc, "mbv_istft_pqmf")
-    for _ in range(10):
+    # untimed warm-up long enough (~35 ms of launches) for the memory / fabric clocks to come up
+    # from idle: measured right after an idle period the same launch is 12-15 % slower
+    # (scripts/istft_state.py)
+    for _ in range(warm):
         launch()
     # several event-bracketed batches; the median batch is reported (single batches on this pool
     # scatter by +-5 % with clock / cache state)
