@@ -6,7 +6,12 @@
 //   p      = softmax_j s
 //   o_i    = sum_j p[i,j] v_j + sum_{r=-4..4} p[i,i+r] Ev[r+4]
 //
-// One wave per (32-query tile, head, utterance).  The score tile is computed
+// One workgroup of NW = 2 waves per (32-query tile, head, utterance); wave w owns key tiles
+// w, w + NW, ...  At T ~ 200 (7 key tiles, 896 workgroups at batch 64) a tile's work is a
+// latency-bound chain and there are fewer workgroups than SIMDs, so the chain is split across
+// waves; the waves meet twice through LDS: the softmax statistics after pass 1, the partial
+// O^T / band weights after pass 2.  (Measured: 1 wave 205 us, 2 waves see profiles/README.md;
+// 4 waves need 2 rounds of workgroups at 213 registers per lane and are slower.)  The score tile is computed
 // TRANSPOSED (S^T = K^T Q, keys on the accumulator rows, queries on the lanes)
 // so that (a) both MFMA operands are read time-contiguous straight from the
 // [B, C, T] activations, (b) the softmax reductions run down a lane's own
@@ -26,8 +31,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int acc_row(int reg, int hl) { return (reg & 3) + 8 * (reg >> 2) + 4 * hl; }
 
+constexpr int ATT_NW = 2;          // waves per workgroup (key tiles are dealt round-robin)
+
 template <int DT>
-__global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float* __restrict__ qkv,
                                                            const float* __restrict__ emb_k,
                                                            const float* __restrict__ emb_v,
                                                            const int* __restrict__ lens,
@@ -35,9 +42,14 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
                                                            int T) {
   constexpr int DMAX = DT * 32;
   constexpr int VS = 33;                              // padded LDS row: conflict-free column reads
-  __shared__ float Vs[DMAX * VS];
+  constexpr int NW = ATT_NW;
+  constexpr int PER = DT * 16 + 9;                     // floats per lane in the final reduction
+  constexpr int VALL = NW * DMAX * VS > (NW - 1) * PER * 64 ? NW * DMAX * VS : (NW - 1) * PER * 64;
+  __shared__ float Vall[VALL];                         // per-wave V tile; reused for the final reduction
+  __shared__ float stat[NW][2][64];                    // per-wave (max, sum) of pass 1
 
-  const int lane = threadIdx.x, hl = lane >> 5, l31 = lane & 31;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, l31 = lane & 31;
+  float* const Vs = Vall + wave * DMAX * VS;
   const int b = blockIdx.z, head = blockIdx.y;
   const int d = H / n_heads;
   const int tq0 = blockIdx.x * 32;
@@ -49,6 +61,18 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
   const float* kb = qb + (int64_t)H * T;
   const float* vb = kb + (int64_t)H * T;
   const int nsteps = d / 2;                           // MFMA k-steps over the head dim
+  // K / V rows are read through raw buffer descriptors of this (utterance, head) slice: one 32-bit
+  // lane offset per tile + a scalar row offset per k-step.  With 64-bit pointers hipcc hoists 2 x 48
+  // row addresses per operand out of the key-tile loop and the kernel needs > 400 registers
+  // (1 wave / SIMD, every latency exposed).  Out-of-range lanes (keys >= T) use an offset past the
+  // slice and read 0.
+  constexpr int kRsrcFlags = 0x00020000;
+  constexpr int kOob = 0x7ffffff0;
+  const __amdgpu_buffer_rsrc_t krsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, d * T * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t vrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, d * T * 4, kRsrcFlags);
+  const int row2 = 2 * T * 4;                         // bytes between k-steps (two rows)
 
   // Q fragments (B operand): B[k = 2s+hl][j = l31] = q[2s+hl][tq] / sqrt(d)
   float qf[DMAX / 2];
@@ -92,9 +116,11 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
     const int tkl = tk0 + l31;
     // all K fragments of the tile first (one latency round), then the MFMA chain
     float kf[DMAX / 2];
+    const int koff = tkl < T ? (hl * T + tkl) * 4 : kOob;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      kf[s] = (s < nsteps && tkl < T) ? kb[(int64_t)(2 * s + hl) * T + tkl] : 0.f;
+      kf[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krsrc, koff, s * row2, 0))
+                         : 0.f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
       if (s < nsteps) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], S, 0, 0, 0);
@@ -116,7 +142,7 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
 
   // ---- pass 1: row max and sum ----------------------------------------------
   float mx = -INFINITY, sum = 0.f;
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt = wave; kt < ntiles; kt += NW) {
     f32x16 S;
     score_tile(kt, S);
     float tmax = S[0];
@@ -139,6 +165,23 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
     sum = a + c;
     mx = mall;
   }
+  // combine the waves' statistics (every wave folds them in the same order -> identical values)
+  stat[wave][0][lane] = mx;
+  stat[wave][1][lane] = sum;
+  __syncthreads();
+  {
+    float mall = stat[0][0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mall = fmaxf(mall, stat[w][0][lane]);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float mw = stat[w][0][lane];
+      tot += mw > -INFINITY ? stat[w][1][lane] * expf(mw - mall) : 0.f;
+    }
+    mx = mall;
+    sum = tot;
+  }
   const float rsum = 1.f / sum;
 
   // ---- pass 2: O^T = V P^T, band weights -------------------------------------
@@ -151,7 +194,7 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
 #pragma unroll
   for (int q = 0; q < 9; ++q) wb[q] = 0.f;
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt = wave; kt < ntiles; kt += NW) {
     const int tk0 = kt * 32;
     f32x16 S;
     score_tile(kt, S);
@@ -166,15 +209,17 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
         for (int q = 0; q < 9; ++q) wb[q] += (rr == q) ? S[r] : 0.f;
       }
     }
-    // stage V[dd][tk0..tk0+31] -> Vs[dd][.]
-    __syncthreads();
+    // stage V[dd][tk0..tk0+31] -> this wave's Vs[dd][.]  (wave-private: the LDS accesses of one
+    // wave are ordered, no workgroup barrier — the waves run different trip counts)
+    const int voff = tk0 + l31 < T ? (hl * T + tk0 + l31) * 4 : kOob;
 #pragma unroll
     for (int it = 0; it < DMAX / 2; ++it) {
       const int dd = it * 2 + hl;
-      const int tk = tk0 + l31;
-      Vs[dd * VS + l31] = (dd < d && tk < T) ? vb[(int64_t)dd * T + tk] : 0.f;
+      Vs[dd * VS + l31] = it < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, voff, it * row2, 0))
+                                      : 0.f;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int tkl = acc_row(s, hl);             // key (within tile) this half supplies at k-step s
@@ -187,6 +232,30 @@ __global__ __launch_bounds__(64) void rel_attention_kernel(const float* __restri
   }
 #pragma unroll
   for (int q = 0; q < 9; ++q) wb[q] += __shfl_xor(wb[q], 32);
+
+  // ---- fold the waves' partial O^T / band weights into wave 0 ------------------
+  __syncthreads();                                    // every wave is done with its V tile
+  if (wave > 0) {
+    float* dst = Vall + ((wave - 1) * PER) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = O[t][r];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dst[(DT * 16 + q) * 64] = wb[q];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    const float* src = Vall + ((w - 1) * PER) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] += src[(t * 16 + r) * 64];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wb[q] += src[(DT * 16 + q) * 64];
+  }
 
   // ---- relative values + store ------------------------------------------------
   float* ob = o + ((int64_t)b * H + head * d) * T;
@@ -210,10 +279,10 @@ void launch_rel_attention(const float* qkv, const float* emb_k, const float* emb
                           hipStream_t s) {
   const int d = H / n_heads;
   dim3 grid((T + 31) / 32, n_heads, B);
-  if (d <= 32) hipLaunchKernelGGL((rel_attention_kernel<1>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
-  else if (d <= 64) hipLaunchKernelGGL((rel_attention_kernel<2>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
-  else if (d <= 96) hipLaunchKernelGGL((rel_attention_kernel<3>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
-  else hipLaunchKernelGGL((rel_attention_kernel<4>), grid, dim3(64), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  if (d <= 32) hipLaunchKernelGGL((rel_attention_kernel<1>), grid, dim3(64 * ATT_NW), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else if (d <= 64) hipLaunchKernelGGL((rel_attention_kernel<2>), grid, dim3(64 * ATT_NW), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else if (d <= 96) hipLaunchKernelGGL((rel_attention_kernel<3>), grid, dim3(64 * ATT_NW), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
+  else hipLaunchKernelGGL((rel_attention_kernel<4>), grid, dim3(64 * ATT_NW), 0, s, qkv, emb_k, emb_v, lens, o, H, n_heads, T);
 }
 
 }  // namespace mbv
