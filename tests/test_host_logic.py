@@ -147,3 +147,9 @@ def test_bench_flop_model_matches_survey():
     _, mini = config_for("ljs_mini_mb_istft_vits")
     assert abs(bench.decoder_flops_per_frame(mini) / 1e6 - 36.8) < 0.1
     assert bench.ISTFT_BYTES_PER_FRAME == 5632
+
+
+def test_graft_entry_build_runs_without_gpu():
+    """`__graft_entry__.build()` is the driver's does-it-build check on the CPU container."""
+    import __graft_entry__ as g
+    g.build()
