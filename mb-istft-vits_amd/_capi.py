@@ -65,6 +65,9 @@ def lib():
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; "
                            "g.build()'` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64; loading this library before torch would bring in the
+    # system HIP runtime as a second instance, which then sees no device ("no HIP device visible")
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64p, fp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
     L.mbv_abi_version.restype = i32
