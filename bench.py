@@ -73,13 +73,17 @@ def main():
 
     import torch.distributed as dist
     from mb_istft_vits_amd import models, utils, synth, dist as mdist, spec as mspec
-    if world > 1:
+    # MBV_BENCH_FORCE_DIST=1: take the sharded (RCCL) code path even with one rank — the rehearsal a
+    # one-GPU box allows for broadcast / all-reduce / all-gather on the real backend
+    dist_on = world > 1 or bool(os.environ.get("MBV_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("MBV_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     hps = utils.get_hparams_from_file(utils.builtin_config(args.config))
     net = models.SynthesizerTrn(59, hps.data.filter_length // 2 + 1,
@@ -89,7 +93,7 @@ def main():
     sr = hps.data.sampling_rate
     # ---- weights: rank 0 generates, RCCL broadcast to the rest -----------------
     sd_np = synth.make_state_dict(cfg, 1234) if rank == 0 else None
-    if world > 1:
+    if dist_on:
         shapes = mspec.param_shapes(cfg)
         sd = mdist.broadcast_state_dict(
             {k: torch.from_numpy(v) for k, v in sd_np.items()} if rank == 0 else None, shapes, dev)
@@ -104,14 +108,14 @@ def main():
     sid = torch.from_numpy(sid_np).to(dev) if sid_np is not None else None
 
     def step():
-        if world > 1:
+        if dist_on:
             o, ylen = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1)
         else:
             (o, *_), ylen = net.infer_with_lengths(x, xl, sid, noise_scale=0, length_scale=1)
         return o, ylen
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -127,7 +131,7 @@ def main():
         istft_ms.append(i)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -230,7 +234,7 @@ def main():
         if cpu:
             line["gpu_over_cpu_rtf"] = round(cpu["rtf"] / line["rtf"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -63,6 +63,8 @@ def gather_waveforms(o_local, ylen_local, shard_sizes):
     y_all = torch.empty(world * bmax, dtype=ylen_local.dtype, device=dev)
     dist.all_gather_into_tensor(o_all, rows.contiguous())
     dist.all_gather_into_tensor(y_all, ylen_local.contiguous())
+    if all(n == bmax for n in shard_sizes):          # equal shards: the gathered buffer is the result
+        return o_all.unsqueeze(1), y_all
     keep = torch.cat([torch.arange(r * bmax, r * bmax + n, device=dev) for r, n in enumerate(shard_sizes)])
     return o_all[keep].unsqueeze(1), y_all[keep]
 
