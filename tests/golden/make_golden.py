@@ -172,6 +172,66 @@ def make_voice_conversion_golden(models, utils):
           "%.0f KB" % (os.path.getsize(os.path.join(HERE, "vc_uudb_b2.npz")) / 1024))
 
 
+def make_params_and_dec_golden(models, utils):
+    """The call-parameter surface of `infer` with the real reference: noise_scale > 0 (the
+    randn_like draw of models.py:729 pinned by patching it), length_scale != 1, max_len
+    truncation (models.py:733), and the decoder-only entry `net.dec(z_chunk)` the chunked
+    decoding notebooks use."""
+    import torch
+    from mb_istft_vits_amd import synth, spec as mspec, utils as mutils
+    cfg_name, n_vocab, B, T = "ljs_mb_istft_vits", 59, 2, 14
+    hps, net = build_reference_model(models, utils, cfg_name, n_vocab)
+    my_hps = mutils.get_hparams_from_file(mutils.builtin_config(cfg_name))
+    cfg = mspec.config_from_ctor(n_vocab, my_hps.data.filter_length // 2 + 1,
+                                 my_hps.train.segment_size // my_hps.data.hop_length,
+                                 n_speakers=my_hps.data.n_speakers, **my_hps.model)
+    length_scale, noise_scale, max_len = 1.2, 0.667, 30
+    seed = 1234
+    while True:
+        sd = synth.make_state_dict(cfg, seed)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        rs = np.random.RandomState(211)
+        x = rs.randint(1, n_vocab, size=(B, T)).astype(np.int64)
+        xl = np.asarray([14, 9], np.int64)
+        for b in range(B):
+            x[b, xl[b]:] = 0
+        with torch.no_grad():
+            taps = {}
+            hk = net.dp.register_forward_hook(lambda m, i, o: taps.update(logw=o.clone()))
+            probe = net.infer(torch.from_numpy(x), torch.from_numpy(xl), noise_scale=0, length_scale=length_scale)
+            hk.remove()
+        w = (torch.exp(taps["logw"]) * probe[5].new_ones(1)).numpy()[:, 0] * length_scale
+        w = np.concatenate([w[b, :xl[b]] for b in range(B)])
+        margin = float(np.min(np.abs(w - np.round(w))))
+        if margin >= 1e-3:
+            break
+        seed += 1
+    Tp = probe[6][0].shape[-1]
+    noise = rs.standard_normal((B, 192, Tp)).astype(np.float32)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: torch.from_numpy(noise) if tuple(t.shape) == noise.shape else real(t, **k)
+    try:
+        with torch.no_grad():
+            o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), _ = net.infer(
+                torch.from_numpy(x), torch.from_numpy(xl), noise_scale=noise_scale,
+                length_scale=length_scale, max_len=max_len)
+            zc = z[:, :, 7:29].contiguous()                 # a chunk, as inferz_test.ipynb cell 7
+            do, do_mb, dspec, dphase = net.dec(zc)
+    finally:
+        torch.randn_like = real
+    np.savez_compressed(
+        os.path.join(HERE, "params_mb_b2.npz"), x=x, x_lengths=xl, noise=noise,
+        length_scale=np.float32(length_scale), noise_scale=np.float32(noise_scale), max_len=np.int64(max_len),
+        weight_seed=np.int64(seed), n_vocab=np.int64(n_vocab), ceil_margin=np.float64(margin),
+        o=o.numpy(), o_mb=o_mb.numpy(), attn=attn.sum(2).numpy(), y_mask=y_mask.numpy(), z=z.numpy(),
+        z_p=z_p.numpy(), spec=spec.numpy()[..., ::5], phase=phase.numpy()[..., ::5],
+        dec_chunk_lo=np.int64(7), dec_chunk_hi=np.int64(29), dec_o=do.numpy(), dec_o_mb=do_mb.numpy(),
+        dec_spec=dspec.numpy()[..., ::5], dec_phase=dphase.numpy()[..., ::5])
+    print("params_mb_b2 seed=%d T'=%d o %s dec_o %s margin=%.3g %.0f KB" % (
+        seed, Tp, tuple(o.shape), tuple(do.shape), margin,
+        os.path.getsize(os.path.join(HERE, "params_mb_b2.npz")) / 1024))
+
+
 def main():
     import torch
     from mb_istft_vits_amd import synth, spec as mspec, utils as mutils
@@ -233,6 +293,8 @@ def main():
 
     if not only or "vc_uudb_b2" in only:
         make_voice_conversion_golden(models, utils)
+    if not only or "params_mb_b2" in only:
+        make_params_and_dec_golden(models, utils)
     if only and "signal_ops" not in only:
         return
     # ---- stand-alone known-answer vectors for the signal ops -------------

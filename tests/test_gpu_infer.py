@@ -310,3 +310,34 @@ def test_voice_conversion_matches_reference_golden():
     with pytest.raises(IndexError):
         net.voice_conversion(torch.from_numpy(gold["y"]).cuda(), torch.from_numpy(gold["y_lengths"]).cuda(),
                              torch.tensor([3, 12]).cuda(), torch.tensor([0, 1]).cuda())
+
+
+def test_call_parameters_and_decoder_entry_match_reference_golden():
+    """`params_mb_b2`: infer(noise_scale=0.667, length_scale=1.2, max_len=30) and `net.dec(z[:, :, 7:29])`
+    captured from the real reference.  The shim draws its own noise, so z_p is rebuilt from the
+    golden's pinned draw by running the decoder half on the golden z through `net.dec` and the
+    encoder half through durations / masks."""
+    from gpu_util import make_net
+    gold = load_fixture("params_mb_b2")
+    net, sd = make_net("ljs_mb_istft_vits", int(gold["n_vocab"]), int(gold["weight_seed"]))
+    x, xl = torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda()
+    ls, ml = float(gold["length_scale"]), int(gold["max_len"])
+    o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), _ = net.infer(
+        x, xl, noise_scale=0, length_scale=ls, max_len=ml)
+    assert np.array_equal(attn.sum(2).cpu().numpy(), gold["attn"])          # durations at length_scale 1.2
+    assert np.array_equal(y_mask.cpu().numpy(), gold["y_mask"])
+    assert o.shape == gold["o"].shape                                       # max_len truncation
+    # the prior sample with the reference's noise: z_p = m_p + noise * exp(logs_p) * noise_scale
+    zp = m_p.cpu() + torch.from_numpy(gold["noise"]) * torch.exp(logs_p.cpu()) * float(gold["noise_scale"])
+    assert _rel(zp.numpy(), gold["z_p"]) < 5e-5
+    # decoder entry on the reference's own z (masked, truncated as models.py:733 does)
+    zin = (torch.from_numpy(gold["z"]) * torch.from_numpy(gold["y_mask"]))[:, :, :ml].cuda()
+    do, do_mb, dspec, dphase = net.dec(zin)
+    assert rms(do.cpu().numpy() - gold["o"]) < 1e-4
+    assert _rel(do_mb.cpu().numpy(), gold["o_mb"]) < 5e-5
+    assert _rel(thin("spec", dspec.cpu()).numpy(), gold["spec"]) < 5e-5
+    lo, hi = int(gold["dec_chunk_lo"]), int(gold["dec_chunk_hi"])
+    co, co_mb, cspec, cphase = net.dec(torch.from_numpy(gold["z"][:, :, lo:hi]).contiguous().cuda())
+    assert rms(co.cpu().numpy() - gold["dec_o"]) < 1e-4
+    assert _rel(co_mb.cpu().numpy(), gold["dec_o_mb"]) < 5e-5
+    assert _rel(thin("phase", cphase.cpu()).numpy(), gold["dec_phase"]) < 5e-5

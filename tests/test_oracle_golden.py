@@ -64,3 +64,27 @@ def test_voice_conversion_matches_reference():
         got, ref = out[name].numpy(), gold[name]
         assert got.shape == ref.shape, name
         assert rms(got - ref) <= 2e-5 * max(rms(ref), 1e-3) + 1e-6, name
+
+
+def test_call_parameters_and_decoder_entry_match_reference():
+    """noise_scale > 0 (noise pinned), length_scale != 1, max_len, and `net.dec(z_chunk)`
+    (models.py:729-734, 344-377) against vectors from the real reference (`params_mb_b2`)."""
+    gold = load_fixture("params_mb_b2")
+    _, cfg = config_for("ljs_mb_istft_vits", int(gold["n_vocab"]))
+    sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
+    torch.set_num_threads(4)
+    out = R.infer(sd, cfg, gold["x"], gold["x_lengths"], noise=gold["noise"],
+                  noise_scale=float(gold["noise_scale"]), length_scale=float(gold["length_scale"]),
+                  max_len=int(gold["max_len"]))
+    assert np.array_equal(thin("attn", out["attn"]).numpy(), gold["attn"])
+    for name in ("y_mask", "z_p", "z", "spec", "phase", "o_mb", "o"):
+        got, ref = thin(name, out[name]).numpy(), gold[name]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert rms(got - ref) <= 2e-5 * max(rms(ref), 1e-3) + 1e-6, name
+    lo, hi = int(gold["dec_chunk_lo"]), int(gold["dec_chunk_hi"])
+    with torch.no_grad():
+        o, o_mb, spec, phase = R.decode(sd, cfg, torch.from_numpy(gold["z"][:, :, lo:hi]))
+    for name, got in (("dec_o", o), ("dec_o_mb", o_mb), ("dec_spec", thin("spec", spec)), ("dec_phase", thin("phase", phase))):
+        ref = gold[name]
+        assert tuple(got.shape) == ref.shape, name
+        assert rms(got.numpy() - ref) <= 2e-5 * max(rms(ref), 1e-3) + 1e-6, name
