@@ -341,3 +341,37 @@ def test_call_parameters_and_decoder_entry_match_reference_golden():
     assert rms(co.cpu().numpy() - gold["dec_o"]) < 1e-4
     assert _rel(co_mb.cpu().numpy(), gold["dec_o_mb"]) < 5e-5
     assert _rel(thin("phase", cphase.cpu()).numpy(), gold["dec_phase"]) < 5e-5
+
+
+def test_large_batch_and_long_utterance_index_paths():
+    """Sizes well past BASELINE's: (a) batch 520 x 200 tokens on the full config — rows of the big run
+    equal, bitwise, the same utterances run as a batch of 8 padded to the same T' (the 128-channel
+    decoder activations are > 2^31 bytes each, so 32-bit offset slips would show); (b) two 1 200-token
+    utterances (T' ~ 3 500, 0.9 M samples each) on the mini config against the oracle."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits")
+    x, xl, _ = synth.synthetic_batch(net.cfg, 520, 200, seed=5, ragged=True)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    (o, _, spec, _, _, _, (z, _, _, _), _), ylen = net.infer_with_lengths(xg, xlg, noise_scale=0, length_scale=1)
+    Tp = z.shape[-1]
+    assert torch.isfinite(o).all() and o.shape == (520, 1, 256 * Tp)
+    assert 520 * 128 * 16 * Tp * 4 > 2 ** 31                # bytes of one [B, 128, 16 T'] activation
+    r = net._run(xg[510:518], xlg[510:518], None, 0, 1, None, True, frames_hook=lambda t: Tp)
+    assert torch.equal(r[0], o[510:518]) and torch.equal(r[2], spec[510:518])
+    del o, spec, z, r
+    torch.cuda.empty_cache()
+
+    net, sd = make_net("ljs_mini_mb_istft_vits", seed=1260)
+    torch.set_num_threads(16)
+    for attempt in range(6):
+        x, xl, _ = synth.synthetic_batch(net.cfg, 2, 1200, seed=77 + attempt, ragged=True)
+        ref = R.infer(sd, net.cfg, x, xl)
+        w = (torch.exp(ref["logw"]) * ref["x_mask"]).numpy()[ref["x_mask"].numpy() > 0]
+        if np.min(np.abs(w - np.round(w))) >= 2e-4:
+            break
+    (o, *_), ylen = net.infer_with_lengths(torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda(),
+                                           noise_scale=0, length_scale=1)
+    assert np.array_equal(ylen.cpu().numpy(), ref["y_lengths"].numpy())
+    assert o.shape == ref["o"].shape and o.shape[-1] > 800000
+    assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
