@@ -80,6 +80,8 @@ struct mbv_model {
   PVec filt;                 // synthesis-bank table of the fused iSTFT+PQMF kernel (352 floats)
 
   // scratch
+  float* conv_ws = nullptr; size_t conv_ws_floats = 0;   // split-K partials of small conv launches
+  unsigned* conv_cnt = nullptr; int conv_ncnt = 0;        // one ticket counter per tile (zero between launches)
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
@@ -732,6 +734,7 @@ ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x
   a.pad_left = (p.K - 1) * dil / 2;
   a.in_slope = 1.f;
   a.y = y; a.y_bstride = y_bstride; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
+  a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   return a;
 }
 
@@ -995,6 +998,19 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   for (auto& e : m->evk)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   m->ev_ok = true;
+  {   // split-K scratch of small conv launches: 64 MB of partials, 8192 ticket counters (zeroed once;
+      // the kernel resets a counter when its last split has arrived)
+    constexpr size_t kWsFloats = (size_t)16 << 20;
+    constexpr int kCounters = 8192;
+    if (hipMalloc((void**)&m->conv_ws, kWsFloats * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&m->conv_cnt, kCounters * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(m->conv_cnt, 0, kCounters * sizeof(unsigned)) != hipSuccess) {
+      mbv_destroy(m);
+      return bad("hipMalloc of the split-K workspace failed");
+    }
+    m->conv_ws_floats = kWsFloats;
+    m->conv_ncnt = kCounters;
+  }
   *out = m;
   return 0;
 }
@@ -1003,6 +1019,8 @@ void mbv_destroy(mbv_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->cfg.device);
   if (m->darena) (void)hipFree(m->darena);
+  if (m->conv_ws) (void)hipFree(m->conv_ws);
+  if (m->conv_cnt) (void)hipFree(m->conv_cnt);
   if (m->scrA) (void)hipFree(m->scrA);
   if (m->scrB) (void)hipFree(m->scrB);
   if (m->user_tab) (void)hipFree(m->user_tab);
@@ -1501,6 +1519,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   a.w = dw; a.bias = db; a.M = Cout; a.Mpad = Mpad; a.K = K; a.dil = dilation;
   a.pad_left = (K - 1) * dilation / 2; a.in_slope = in_slope;
   a.y = y; a.y_bstride = (int64_t)Cout * T; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
+  a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   launch_conv1d(a, s);
   HIPCHK(m, hipStreamSynchronize(s));
   HIPCHK(m, hipFree(dw));

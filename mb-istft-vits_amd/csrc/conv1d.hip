@@ -43,6 +43,74 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// Start values of a wave's accumulators: everything the epilogue would otherwise have to READ
+// after the MFMA loop (residual, running ResBlock sum, the tensor a flow layer updates in place);
+// zero for the epilogues that read nothing.  `full`: the wave's patch lies inside [M, T].
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvArgs& a, int b, int wrow0,
+                                              int t0, int wn, int hl, int l31, bool full,
+                                              int64_t lane_off) {
+  constexpr bool kInit = EPI == EPI_RESID || EPI == EPI_RESID_ACC || EPI == EPI_RES_SKIP || EPI == EPI_COUPLE;
+    if ((EPI == EPI_RESID || EPI == EPI_RESID_ACC) && full) {
+      const float* pr = a.res + (int64_t)b * a.res_bstride + lane_off;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* q = pr + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j][r] = q[j * 32];
+        }
+      if (EPI == EPI_RESID_ACC && a.accum_in) {
+        // second operand through temporaries, half a patch at a time: two waits instead of one
+        // per element (a load feeding an add right away serialises the whole initialisation)
+        const float* pa = a.accum_in + (int64_t)b * a.y_bstride + lane_off;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          float tmp[16][WN];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float* q = pa + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) tmp[r][j] = q[j * 32];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j][r] += tmp[r][j];
+        }
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          float v0 = 0.f;
+          if constexpr (kInit) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
+            if (row < a.M && t < a.T) {
+              if constexpr (EPI == EPI_RESID) {
+                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
+              } else if constexpr (EPI == EPI_RESID_ACC) {
+                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
+                if (a.accum_in) v0 += a.accum_in[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+              } else if constexpr (EPI == EPI_RES_SKIP) {
+                if (row < a.split) v0 = a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+                else if (a.skip_accum) v0 = a.skip[((int64_t)b * (a.M - a.split) + (row - a.split)) * a.T + t];
+              } else {   // EPI_COUPLE: y' = mask * sign * (sign * y + conv + bias)
+                v0 = a.couple_sign * a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
+              }
+            }
+          }
+          acc[i][j][r] = v0;
+        }
+      }
+    }
+}
+
 // NWN = waves along time.  NWN == 2: 256 threads, single LDS buffer, 2 barriers per chunk,
 // two workgroups per CU (short sequences / small launches).  NWN == 4: 512 threads = one
 // workgroup per CU with 2 waves per SIMD, the weight slab shared by twice as many columns,
@@ -58,7 +126,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // No staging registers are live across the epilogue.
 template <int WM, int WN, int CK, int NWN, int EPI>
 __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
-                                                                   int tiles_y, int total_tiles) {
+                                                                   int tiles_y, int total_tiles,
+                                                                   int ksplit) {
   constexpr int NT = 128 * NWN;          // threads
   constexpr bool DB = NWN == 4;          // double-buffered LDS
   constexpr int BM = 64 * WM;            // 2 waves x WM tiles of 32 rows
@@ -189,16 +258,29 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   // staging cursor: the next chunk to load (runs ahead of the tile being multiplied)
   const int nck = a.Cin / CK;
   const bool stage0_only = a.debug == 1 || a.debug == 4;      // timing experiments: stage chunk 0 of a tile only
-  int s_tile = blockIdx.x, s_c = 0;
+  // Split-K (small launches only, S = ksplit > 1): a work unit is (tile, split); split sp owns chunks
+  // [sp nck / S, (sp + 1) nck / S).  Units of a tile leave their partial accumulators in a
+  // workspace; the last one to arrive (ticket counter) sums them in split order on top of the
+  // start values and runs the epilogue.  S == 1: a unit is a tile.
+  const int S = NWN == 2 ? ksplit : 1;             // the 512-thread shape is only picked for launches that fill the chip
+  const int total_units = total_tiles * S;
+  __shared__ int s_ticket;
+  int s_unit = blockIdx.x;
+  int s_c = (s_unit % S) * nck / S, s_end = (s_unit % S + 1) * nck / S;
   int pend_cn = -1;                      // channel offset of the chunk held in wreg/xreg (-1: none)
 #define MBV_ISSUE_NEXT()                                                                     \
-  if (s_tile < total_tiles) {                                                                \
-    if (s_c == 0) MBV_SETUP_TILE(s_tile);                                                    \
-    if (s_c == 0 || !stage0_only) {                                                          \
+  if (s_unit < total_units) {                                                                \
+    const bool first_ = s_c == (s_unit % S) * nck / S;                                       \
+    if (first_) MBV_SETUP_TILE(s_unit / S);                                                  \
+    if (first_ || !stage0_only) {                                                            \
       MBV_ISSUE(s_c * CK);                                                                   \
       pend_cn = s_c * CK;                                                                    \
     }                                                                                        \
-    if (++s_c == nck) { s_c = 0; s_tile += gridDim.x; }                                      \
+    if (++s_c == s_end) {                                                                    \
+      s_unit += gridDim.x;                                                                   \
+      s_c = (s_unit % S) * nck / S;                                                          \
+      s_end = (s_unit % S + 1) * nck / S;                                                    \
+    }                                                                                        \
   }
 
   // ---- prime: chunk 0 of the first tile -> LDS buffer 0 -------------------------
@@ -212,7 +294,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   __syncthreads();
 
   int q = 0;                             // chunks multiplied so far (LDS buffer parity)
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int tile = unit / S, sp = unit % S;
+    const int c_lo = sp * nck / S, c_hi = (sp + 1) * nck / S;
     const int tx = tile % tiles_x, rest = tile / tiles_x;
     const int b = rest / tiles_y, m0 = (rest % tiles_y) * BM, t0 = tx * BN;
     const int wrow0 = m0 + wm * 32 * WM;
@@ -227,7 +311,6 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
     // to reach L2: an epilogue that interleaves the two is a chain of round trips (measured: a
     // quarter of a k=3 conv).  With the reads up here the epilogue is stores only.
     f32x16 acc[WM][WN];
-    constexpr bool kInit = EPI == EPI_RESID || EPI == EPI_RESID_ACC || EPI == EPI_RES_SKIP || EPI == EPI_COUPLE;
     // bias (+ per-utterance row terms) of row wrow0 + lane, handed out by cross-lane reads below
     float rowc = 0.f;
     {
@@ -246,71 +329,23 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           if (a.res_chan_add) rowc += a.res_chan_add[b * a.M + row];
       }
     }
-    // a wave whose 32*WM x 32*WN patch lies wholly inside [M, T] takes the unguarded paths below
-    // and in the epilogue (no per-element exec masking, loads issued back to back)
+    // a wave whose 32*WM x 32*WN patch lies wholly inside [M, T] takes the unguarded paths in
+    // conv_acc_init and in the epilogue (no per-element exec masking, loads issued back to back)
     const bool full = wrow0 + 32 * WM <= a.M && t0 + wn * 32 * WN + 32 * WN <= a.T;
     const int64_t lane_off = (int64_t)(wrow0 + 4 * hl) * a.T + t0 + wn * 32 * WN + l31;   // element (k = 0, j = 0)
-    if ((EPI == EPI_RESID || EPI == EPI_RESID_ACC) && full) {
-      const float* pr = a.res + (int64_t)b * a.res_bstride + lane_off;
+    if (S == 1) {
+      conv_acc_init<WM, WN, EPI>(acc, a, b, wrow0, t0, wn, hl, l31, full, lane_off);
+    } else {                                         // split-K: partial sums start from zero
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float* q = pr + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j][r] = q[j * 32];
-        }
-      if (EPI == EPI_RESID_ACC && a.accum_in) {
-        // second operand through temporaries, half a patch at a time: two waits instead of one
-        // per element (a load feeding an add right away serialises the whole initialisation)
-        const float* pa = a.accum_in + (int64_t)b * a.y_bstride + lane_off;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          float tmp[16][WN];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float* q = pa + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
-#pragma unroll
-            for (int j = 0; j < WN; ++j) tmp[r][j] = q[j * 32];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j][r] += tmp[r][j];
-        }
-      }
-    } else {
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          float v0 = 0.f;
-          if constexpr (kInit) {
-            const int t = t0 + wn * 32 * WN + j * 32 + l31;
-            if (row < a.M && t < a.T) {
-              if constexpr (EPI == EPI_RESID) {
-                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
-              } else if constexpr (EPI == EPI_RESID_ACC) {
-                v0 = a.res[(int64_t)b * a.res_bstride + (int64_t)row * a.T + t];
-                if (a.accum_in) v0 += a.accum_in[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
-              } else if constexpr (EPI == EPI_RES_SKIP) {
-                if (row < a.split) v0 = a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
-                else if (a.skip_accum) v0 = a.skip[((int64_t)b * (a.M - a.split) + (row - a.split)) * a.T + t];
-              } else {   // EPI_COUPLE: y' = mask * sign * (sign * y + conv + bias)
-                v0 = a.couple_sign * a.y[(int64_t)b * a.y_bstride + (int64_t)row * a.T + t];
-              }
-            }
-          }
-          acc[i][j][r] = v0;
-        }
-      }
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
     if constexpr (DB) { MBV_ISSUE_NEXT(); }   // second chunk of this tile (its first is in LDS)
 
-    for (int c = 0; c < nck; ++c, ++q) {
+    for (int c = c_lo; c < c_hi; ++c, ++q) {
       f32x4* const Xs = lds4 + (DB ? ((q & 1) ? buf_f4 : 0) : 0);           // buffer holding this chunk
       f32x4* const Ws = Xs + G * 2 * XL;
       f32x4* const Xn = lds4 + (DB ? ((q & 1) ? 0 : buf_f4) : 0);           // buffer for the next one
@@ -382,7 +417,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
       if constexpr (DB) {
         if (pend_cn >= 0) { MBV_COMMIT(pend_cn, Xn, Wn); }   // other buffer: last read one barrier ago
         pend_cn = -1;
-        if (c + 1 < nck) { MBV_ISSUE_NEXT(); }               // the last chunk issues AFTER the epilogue
+        if (c + 1 < c_hi) { MBV_ISSUE_NEXT(); }              // the last chunk issues AFTER the epilogue
         __syncthreads();
       } else {
         if (pend_cn >= 0) {
@@ -397,7 +432,41 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
     // ---- epilogue ----------------------------------------------------------
     // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // stores only (see the accumulator initialisation above)
-    const bool skip_epi = a.debug == 4 && acc[0][0][0] != 12345.678f;   // timing experiment: no epilogue traffic
+    bool skip_epi = a.debug == 4 && acc[0][0][0] != 12345.678f;         // timing experiment: no epilogue traffic
+    if (S > 1) {
+      const size_t tile_floats = (size_t)BM * BN;                      // == 16 WM WN NT
+      float* wsu = a.ws + ((size_t)tile * S + sp) * tile_floats + tid;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) wsu[(size_t)((i * WN + j) * 16 + r) * NT] = acc[i][j][r];
+      __threadfence();                                                 // partials visible device-wide ...
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t = atomicAdd(a.counters + tile, 1u);           // ... before the ticket is taken
+        if (t == (unsigned)S - 1) a.counters[tile] = 0;                // self-resetting for the next launch
+        s_ticket = (int)t;
+      }
+      __syncthreads();
+      if (s_ticket != S - 1) {
+        skip_epi = true;
+      } else {
+        __threadfence();                                               // drop stale lines before reading the others' partials
+        conv_acc_init<WM, WN, EPI>(acc, a, b, wrow0, t0, wn, hl, l31, full, lane_off);
+        const float* w0 = a.ws + (size_t)tile * S * tile_floats + tid;
+        for (int sq = 0; sq < S; ++sq) {                               // fixed order: deterministic
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                acc[i][j][r] += w0[(size_t)sq * tile_floats + (size_t)((i * WN + j) * 16 + r) * NT];
+        }
+      }
+    }
     const int T = a.T;
     const int len_out = a.out_lens ? a.out_lens[b] : 0x7fffffff;
     if (skip_epi) {
@@ -517,18 +586,40 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   // 512-thread shape, 2 for the 256-thread one: both are register-limited to 2 waves / SIMD)
   static const int persist = [] { const char* e = getenv("MBV_CONV_PERSIST"); return e ? atoi(e) : 1; }();
   const long slots = 256L * (NWN == 4 ? 1 : 2);
-  const int grid = (int)((persist && total > slots) ? slots : total);
+  // Split-K for launches that fill less than a quarter of the chip (single utterances: 34 tiles of a
+  // 128-channel decoder conv at batch 1): at least two chunks per split, workspace and ticket
+  // counters permitting.  OPT-IN (MBV_CONV_SPLITK=1, the low-latency service setting): the order of
+  // summation then depends on the launch size, so a row computed inside a large batch is no longer
+  // bitwise equal to the same row computed alone (it is within fp32 rounding); the default keeps
+  // that property.  Every parity test passes in either mode.
+  static const int splitk = [] { const char* e = getenv("MBV_CONV_SPLITK"); return e ? atoi(e) : 0; }();
+  int S = 1;
+  const int nck = a.Cin / CK;
+  // an almost empty chip (<= 32 tiles: one utterance) repays splits of two chunks; up to a quarter
+  // full, K loops of >= 16 chunks cut into >= 4-chunk pieces (measured at batch 1 and 8)
+  const bool tiny = total * 16 <= slots;
+  const int min_chunks = tiny ? 2 : 4;
+  if (NWN == 2 && splitk && a.ws && a.counters && total * 4 <= slots && nck >= (tiny ? 4 : 16) &&
+      total <= a.n_counters) {
+    S = (int)(slots / total);
+    if (S > nck / min_chunks) S = nck / min_chunks;
+    if (S > 16) S = 16;
+    while (S > 1 && (size_t)total * S * BM * BN > a.ws_floats) --S;
+    if (S < 1) S = 1;
+  }
+  const long units = total * S;
+  const int grid = (int)((persist && units > slots) ? slots : units);
   ConvArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
   a2.debug = dbg;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the split-K ticket
     attr = true;
   }
   hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,
-                     tiles_x, tiles_y, (int)total);
+                     tiles_x, tiles_y, (int)total, S);
 }
 
 // The epilogue is a compile-time parameter: with a run-time switch inside the unrolled

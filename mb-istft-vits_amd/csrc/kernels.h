@@ -62,6 +62,11 @@ struct ConvArgs {
   float couple_sign;       // COUPLE: -1 reverse (x1 - m), +1 forward (x1 + m)
   int B;
   int debug;               // timing experiments only (MBV_CONV_DEBUG): 1 = no restaging, 3 = no MFMA
+  // split-K scratch (small launches): partial accumulators + one self-resetting ticket per tile
+  float* ws;
+  size_t ws_floats;
+  unsigned* counters;
+  int n_counters;
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for

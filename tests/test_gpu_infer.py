@@ -2,6 +2,10 @@
 vectors captured from the real reference and (b) the oracle on fresh inputs.
 Bar (north-star): waveform within 1e-4 RMS of the reference CPU path at
 noise_scale=0, length_scale=1; durations (ceil) exact."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +14,16 @@ from helpers import FIXTURES, OVERRIDES, SDP_NOISE_SCALE_W, load_fixture, config
 from oracle import ref_infer as R
 
 pytestmark = pytest.mark.gpu
+
+# MBV_CONV_SPLITK=1 (opt-in low-latency mode): the summation order of small launches depends on the
+# launch size, so "same row, different batch" is equal within rounding instead of bitwise
+SPLITK = os.environ.get("MBV_CONV_SPLITK", "0") not in ("", "0")
+
+
+def _same_rows(a, b):
+    if not SPLITK:
+        return torch.equal(a, b)
+    return float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-3)
 
 STAGE_SHAPES = {  # read_stage name -> golden key, shape builder
     "x_enc": "x_enc", "m_text": "m_text", "logs_text": "logs_text", "logw": "logw",
@@ -278,7 +292,7 @@ def test_full_size_batch64_properties():
     o2 = net.infer(xg, xlg, noise_scale=0, length_scale=1)[0]
     assert torch.equal(o, o2)
     r = net._run(xg[40:48], xlg[40:48], None, 0, 1, None, True, frames_hook=lambda t: Tp)
-    assert torch.equal(r[0], o[40:48]) and torch.equal(r[6][0], z[40:48])
+    assert _same_rows(r[0], o[40:48]) and _same_rows(r[6][0], z[40:48])
     torch.set_num_threads(8)
     ref = R.infer(sd, net.cfg, x[[3, 57]], xl[[3, 57]], t_frames=Tp)
     got = o[[3, 57]].cpu().numpy()
@@ -358,7 +372,7 @@ def test_large_batch_and_long_utterance_index_paths():
     assert torch.isfinite(o).all() and o.shape == (520, 1, 256 * Tp)
     assert 520 * 128 * 16 * Tp * 4 > 2 ** 31                # bytes of one [B, 128, 16 T'] activation
     r = net._run(xg[510:518], xlg[510:518], None, 0, 1, None, True, frames_hook=lambda t: Tp)
-    assert torch.equal(r[0], o[510:518]) and torch.equal(r[2], spec[510:518])
+    assert _same_rows(r[0], o[510:518]) and _same_rows(r[2], spec[510:518])
     del o, spec, z, r
     torch.cuda.empty_cache()
 
@@ -375,3 +389,31 @@ def test_large_batch_and_long_utterance_index_paths():
     assert np.array_equal(ylen.cpu().numpy(), ref["y_lengths"].numpy())
     assert o.shape == ref["o"].shape and o.shape[-1] > 800000
     assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
+def test_splitk_low_latency_mode_in_subprocess():
+    """MBV_CONV_SPLITK=1 (split-K over input channels for launches that leave most of the chip idle —
+    the single-utterance service case) is read once per process, so it is exercised in a child:
+    three goldens from the real reference + bitwise run-to-run determinism of the ticketed reduce."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import FIXTURES, OVERRIDES, load_fixture, rms
+from gpu_util import make_net
+for fx in ("mini_b1", "mb_b3", "uudb_b2", "sb_mini_b2"):
+    gold = load_fixture(fx)
+    net, sd = make_net(FIXTURES[fx], int(gold["n_vocab"]), int(gold["weight_seed"]), overrides=OVERRIDES.get(fx))
+    x, xl = torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda()
+    sid = torch.from_numpy(gold["sid"]).cuda() if "sid" in gold else None
+    out = net.infer(x, xl, sid=sid, noise_scale=0, length_scale=1)
+    assert np.array_equal(out[4].sum(2).cpu().numpy(), gold["attn"]), fx
+    err = rms(out[0].cpu().numpy() - gold["o"])
+    assert err < 1e-4, (fx, err)
+    again = net.infer(x, xl, sid=sid, noise_scale=0, length_scale=1)[0]
+    assert torch.equal(again, out[0]), fx
+    print(fx, "rms err %%.2e" %% err)
+print("SPLITK-OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MBV_CONV_SPLITK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SPLITK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
