@@ -12,9 +12,12 @@
 //   modules.py:336-350 (coupling pre/post), models.py:348 (conv_pre k7),
 //   modules.py:216-226 (ResBlock1 convs, leaky-relu fused on the input,
 //   residual add fused on the output), models.py:363-365 (lrelu 0.01 +
-//   ReflectionPad1d((1,0)) + subband_conv_post k7).
+//   ReflectionPad1d((1,0)) + subband_conv_post k7), models.py:321-323 (stride-4
+//   ConvTranspose1d as a 5-tap conv over its output phases, EPI_CONVT),
+//   models.py:222-231 / modules.py:98-111 (posterior encoder, SDP 1x1 convs).
 //
-// Tiling (wave64): block = 4 waves as 2(M) x 2(N); each wave owns WM x WN MFMA
+// Tiling (wave64): block = 2(M) x NWN(N) waves, NWN = 2 (256 threads) or 4 (512 threads,
+// double-buffered LDS); each wave owns WM x WN MFMA
 // tiles of 32x32 (rows = output channels, columns = time).  K loop: Cin in
 // chunks of CK channels (CK/8 groups of 8); per chunk the activated input window
 // and the weight slab are staged in LDS once and reused by all taps.
@@ -31,6 +34,9 @@
 // Staging is an async split (global -> registers -> LDS): all loads of chunk c+1
 // are issued before the MFMA loop of chunk c and committed to LDS after it; the
 // operand reads inside the loop are double-buffered in registers one group ahead.
+// Work distribution: persistent workgroups walk (tile[, K split]) units as one staging stream;
+// epilogue kind is a template parameter; accumulators start from whatever the epilogue would
+// have to read (see conv_acc_init and the notes at the kernel).
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
