@@ -69,10 +69,13 @@ def gather_waveforms(o_local, ylen_local, shard_sizes):
     return o_all[keep].unsqueeze(1), y_all[keep]
 
 
-def sharded_infer(net, x, x_lengths, sid=None, noise_scale=1, length_scale=1, max_len=None):
+def sharded_infer(net, x, x_lengths, sid=None, noise_scale=1, length_scale=1, max_len=None,
+                  noise_scale_w=1.):
     """Every rank passes the SAME full batch (or at least its own block); each
     synthesises its block and all ranks return the full-batch waveform
-    [B, 1, 256 T'max] and y_lengths [B]."""
+    [B, 1, 256 T'max] and y_lengths [B].  With a StochasticDurationPredictor every rank draws the
+    full-batch duration noise (models.py:94) and uses its block, so that ranks seeded alike
+    reproduce the single-process durations."""
     world, rank = dist.get_world_size(), dist.get_rank()
     B = x.shape[0]
     sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
@@ -80,7 +83,10 @@ def sharded_infer(net, x, x_lengths, sid=None, noise_scale=1, length_scale=1, ma
     if hi == lo:
         raise ValueError("batch %d smaller than world size %d" % (B, world))
     dev = net._device()
+    extra = {}
+    if getattr(net.cfg, "use_sdp", False):
+        extra = dict(noise_scale_w=noise_scale_w, noise_w=torch.randn(B, 2, x.shape[1])[lo:hi])
     r = net._run(x[lo:hi], x_lengths[lo:hi], sid[lo:hi] if sid is not None else None, noise_scale,
-                 length_scale, max_len, True, frames_hook=lambda tp: global_max_frames(tp, dev))
+                 length_scale, max_len, True, frames_hook=lambda tp: global_max_frames(tp, dev), **extra)
     o_local, ylen_local = r[0], r[8]
     return gather_waveforms(o_local, ylen_local, sizes)

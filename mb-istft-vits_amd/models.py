@@ -260,7 +260,7 @@ class SynthesizerTrn(nn.Module):
     # ------------------------------------------------------------------ API
     @torch.no_grad()
     def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode,
-             frames_hook=None, noise_scale_w=1.):
+             frames_hook=None, noise_scale_w=1., noise_w=None):
         h = self._ensure_handle()
         L = _capi.lib()
         x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
@@ -269,10 +269,16 @@ class SynthesizerTrn(nn.Module):
         with torch.cuda.device(dev):
             stream = self._stream()
             y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
-            noise_w = None
             if self.cfg.use_sdp:
-                # the reference draws on the default CPU generator and moves it over (models.py:94)
-                noise_w = torch.randn(B, 2, T).to(device=dev, dtype=torch.float32)
+                # the reference draws on the default CPU generator and moves it over (models.py:94);
+                # a sharded caller passes its block of the full-batch draw instead
+                if noise_w is None:
+                    noise_w = torch.randn(B, 2, T)
+                if tuple(noise_w.shape) != (B, 2, T):
+                    raise ValueError("noise_w must be [B, 2, T_text]")
+                noise_w = noise_w.to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                noise_w = None
             _capi.check(h, L.mbv_encode(h, self._ptr(x), self._ptr(x_lengths), self._ptr(sid), B, T,
                                         float(length_scale), self._ptr(noise_w), float(noise_scale_w),
                                         self._ptr(y_lengths), stream),

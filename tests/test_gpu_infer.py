@@ -417,3 +417,26 @@ print("SPLITK-OK")
     env = dict(os.environ, MBV_CONV_SPLITK="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SPLITK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sharded_infer_single_rank_equals_plain_infer_with_sdp():
+    """`dist.sharded_infer` on a one-rank gloo group (the collectives run, on CUDA tensors) returns
+    what `infer` returns — including the StochasticDurationPredictor noise, which the sharded path
+    draws for the full batch and slices (same CPU seed => same durations)."""
+    import socket
+    import torch.distributed as dist
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth, dist as mdist
+    net, sd = make_net("ljs_mini_mb_istft_vits", seed=1271, overrides={"use_sdp": True})
+    x, xl, _ = synth.synthetic_batch(net.cfg, 4, 30, seed=3, ragged=True)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    torch.manual_seed(99)
+    (o_ref, *_), ylen_ref = net.infer_with_lengths(xg, xlg, noise_scale=0, length_scale=1, noise_scale_w=0.5)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        torch.manual_seed(99)
+        o, ylen = mdist.sharded_infer(net, xg, xlg, None, noise_scale=0, length_scale=1, noise_scale_w=0.5)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(ylen, ylen_ref) and torch.equal(o, o_ref)
