@@ -142,6 +142,15 @@ int mbv_decode(mbv_model *m, const float *z, const float *g, int B, int t_frames
  * out fp32 [B, gin] */
 int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, void *stream);
 
+/* ---- run-time options (no reference counterpart) ------------------------------
+ *   "splitk"       1: split the input-channel loop of conv launches that leave most of the chip
+ *                  idle over several workgroups (single-utterance latency: ljs_mb batch 1
+ *                  10.3 -> 6.5 ms).  Deterministic, within fp32 rounding of the default; a row is
+ *                  then no longer bitwise independent of the batch it is computed in.  Default 0
+ *                  (or the MBV_CONV_SPLITK environment variable at mbv_create time).
+ *   "istft_exact"  1: libm transcendentals in the fused iSTFT kernel (default 0 / MBV_ISTFT_EXACT). */
+int mbv_set_option(mbv_model *m, const char *name, int value);
+
 /* ---- stage timers -----------------------------------------------------------
  * replaces the `timings` dict (models.py:698-737): milliseconds of the five
  * stages of the last encode+synthesize pair, from HIP events on `stream`:

@@ -82,6 +82,7 @@ struct mbv_model {
   // scratch
   float* conv_ws = nullptr; size_t conv_ws_floats = 0;   // split-K partials of small conv launches
   unsigned* conv_cnt = nullptr; int conv_ncnt = 0;        // one ticket counter per tile (zero between launches)
+  int splitk = 0;             // option "splitk": split-K for small conv launches (default: MBV_CONV_SPLITK or 0)
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
   float* user_tab = nullptr;   // polyphase table of the stand-alone mbv_istft_pqmf entry
@@ -735,6 +736,7 @@ ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x
   a.in_slope = 1.f;
   a.y = y; a.y_bstride = y_bstride; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
+  a.splitk = m->splitk;
   return a;
 }
 
@@ -992,6 +994,7 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   if (!m) return bad("out of host memory");
   m->cfg = *cfg;
   { const char* e = getenv("MBV_ISTFT_EXACT"); m->exact_math = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = getenv("MBV_CONV_SPLITK"); m->splitk = (e && atoi(e) != 0) ? 1 : 0; }
   build_expected(m);
   for (auto& e : m->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
@@ -1013,6 +1016,14 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   }
   *out = m;
   return 0;
+}
+
+int mbv_set_option(mbv_model* m, const char* name, int value) {
+  if (!m) return 1;
+  if (!name) return m->fail("mbv_set_option: name is NULL");
+  if (!strcmp(name, "splitk")) { m->splitk = value != 0; return 0; }
+  if (!strcmp(name, "istft_exact")) { m->exact_math = value != 0; return 0; }
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact)", name);
 }
 
 void mbv_destroy(mbv_model* m) {
@@ -1520,6 +1531,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   a.pad_left = (K - 1) * dilation / 2; a.in_slope = in_slope;
   a.y = y; a.y_bstride = (int64_t)Cout * T; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
+  a.splitk = m->splitk;
   launch_conv1d(a, s);
   HIPCHK(m, hipStreamSynchronize(s));
   HIPCHK(m, hipFree(dw));

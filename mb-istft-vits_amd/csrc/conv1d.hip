@@ -594,11 +594,11 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   const long slots = 256L * (NWN == 4 ? 1 : 2);
   // Split-K for launches that fill less than a quarter of the chip (single utterances: 34 tiles of a
   // 128-channel decoder conv at batch 1): at least two chunks per split, workspace and ticket
-  // counters permitting.  OPT-IN (MBV_CONV_SPLITK=1, the low-latency service setting): the order of
+  // counters permitting.  OPT-IN (mbv_set_option("splitk", 1) or MBV_CONV_SPLITK=1: the low-latency service setting): the order of
   // summation then depends on the launch size, so a row computed inside a large batch is no longer
   // bitwise equal to the same row computed alone (it is within fp32 rounding); the default keeps
   // that property.  Every parity test passes in either mode.
-  static const int splitk = [] { const char* e = getenv("MBV_CONV_SPLITK"); return e ? atoi(e) : 0; }();
+  const int splitk = a.splitk;
   int S = 1;
   const int nck = a.Cin / CK;
   // an almost empty chip (<= 32 tiles: one utterance) repays splits of two chunks; up to a quarter

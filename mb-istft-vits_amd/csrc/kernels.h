@@ -67,6 +67,7 @@ struct ConvArgs {
   size_t ws_floats;
   unsigned* counters;
   int n_counters;
+  int splitk;              // 1: split-K allowed for this launch (mbv_set_option "splitk" / MBV_CONV_SPLITK)
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for

@@ -443,6 +443,13 @@ class SynthesizerTrn(nn.Module):
                     "mbv_kernel_times_ms")
         return float(buf[0]), float(buf[1])
 
+    def set_option(self, name, value):
+        """Run-time options of the library (`mbv_set_option`): "splitk" (low-latency split-K for
+        small launches), "istft_exact".  Kept across weight refreshes; a
+        handle re-created on another device starts from the defaults again."""
+        h = self._ensure_handle()
+        _capi.check(h, _capi.lib().mbv_set_option(h, name.encode(), int(value)), "mbv_set_option")
+
     def read_stage(self, name):
         """Internal stage tensor of the last call as a flat fp32 tensor (tests/debugging)."""
         h = self._ensure_handle()

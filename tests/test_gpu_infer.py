@@ -440,3 +440,24 @@ def test_sharded_infer_single_rank_equals_plain_infer_with_sdp():
     finally:
         dist.destroy_process_group()
     assert torch.equal(ylen, ylen_ref) and torch.equal(o, o_ref)
+
+
+def test_set_option_splitk_in_process():
+    """`net.set_option("splitk", 1)` (mbv_set_option) switches the low-latency mode per model."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import _capi
+    gold = load_fixture("mb_b3")
+    net, sd = make_net("ljs_mb_istft_vits", int(gold["n_vocab"]), int(gold["weight_seed"]))
+    x, xl = torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda()
+    o0 = net.infer(x, xl, noise_scale=0, length_scale=1)[0]
+    net.set_option("splitk", 1)
+    o1 = net.infer(x, xl, noise_scale=0, length_scale=1)[0]
+    net.set_option("splitk", 0)
+    o2 = net.infer(x, xl, noise_scale=0, length_scale=1)[0]
+    assert rms(o1.cpu().numpy() - gold["o"]) < 1e-4
+    assert float((o1 - o0).abs().max()) < 1e-4
+    if not SPLITK:
+        assert torch.equal(o2, o0)                       # back to the default path, bitwise
+        assert not torch.equal(o1, o0)                   # the split path really ran (other summation order)
+    with pytest.raises(_capi.MbvError):
+        net.set_option("no-such-option", 1)
