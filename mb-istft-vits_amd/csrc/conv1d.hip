@@ -603,7 +603,8 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   const int nck = a.Cin / CK;
   // an almost empty chip (<= 32 tiles: one utterance) repays splits of two chunks; up to a quarter
   // full, K loops of >= 16 chunks cut into >= 4-chunk pieces (measured at batch 1 and 8)
-  const bool tiny = total * 16 <= slots;
+  static const int tiny_div = [] { const char* e = getenv("MBV_SPLITK_TINY"); return e ? atoi(e) : 16; }();
+  const bool tiny = total * (long)tiny_div <= slots;
   const int min_chunks = tiny ? 2 : 4;
   if (NWN == 2 && splitk && a.ws && a.counters && total * 4 <= slots && nck >= (tiny ? 4 : 16) &&
       total <= a.n_counters) {
