@@ -217,7 +217,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "audio samples/sec (22.05 kHz), MB-iSTFT-VITS infer, batch %d per GPU" % B,
+            "metric": "audio samples/sec (%g kHz), MB-iSTFT-VITS infer, batch %d per GPU" % (sr / 1000.0, B),
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
