@@ -169,6 +169,9 @@ def main():
                      "achieved": round(fl / (cm * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(fl / (cm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                      "ms_per_step": round(cm, 3), "flop_per_step": fl}
+        pmc_conv = os.path.join(ROOT, "profiles", "conv_mfma_pmc.json")
+        if os.path.isfile(pmc_conv):             # matrix-pipe busy share from a separate --pmc pass
+            roof_conv["mfma_util_percent_pmc"] = json.load(open(pmc_conv)).get("mfma_util_percent")
 
     # ---- CPU baseline: the oracle ("port") on this box's host cores ------------------
     cpu = None
