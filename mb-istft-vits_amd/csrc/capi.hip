@@ -617,30 +617,31 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
         }
       }
     U.bias = P.vec(std::string(p) + ".bias").off;
-    if (us == 4 && U.Cout % 32 == 0 && U.Cin % 16 == 0) {
-      // The same ConvTranspose1d as ONE 5-tap conv on the conv1d kernel (EPI_CONVT):
-      //   y[co, 4m + r] = sum_ci sum_j W[ci][co][kr + 4j] x[ci, m + sh_r - j],  kr = (r + 6) % 4,
-      //   sh_r = (r + 6 - kr) / 4;  tap tau reads x[m - 2 + tau]  ->  j = sh_r + 2 - tau.
-      // Packed rows: groups of 64 = 16 channels x [phases 0,1 (32 rows) | phases 2,3 (32 rows)],
-      // row k of a half = channel k / 2, phase k % 2.  Tap 4 is zero for the first half, tap 0 for
-      // the second; the kernel skips those MFMAs.
-      const int Mp = 4 * U.Cout;
+    if ((us == 4 || us == 8) && U.Cout % 32 == 0 && U.Cin % 16 == 0) {
+      // The same ConvTranspose1d as ONE (16/us + 1)-tap conv on the conv1d kernel (EPI_CONVT):
+      //   y[co, us m + r] = sum_ci sum_j W[ci][co][kr + us j] x[ci, m + sh_r - j],  kr = (r + pad) % us,
+      //   sh_r = (r + pad - kr) / us;  tap tau reads x[m - pl + tau]  ->  j = sh_r + pl - tau, with
+      //   pl = tpp - 1 - pad / us  (us 4: 5 taps, pl 2;  us 8: 3 taps, pl 1).
+      // Packed rows: groups of 64 = 64/us channels x [first us/2 phases (32 rows) | last us/2 phases
+      // (32 rows)], row k of a half = channel k / (us/2), phase k % (us/2).  The last tap is zero for
+      // the first half, tap 0 for the second; the kernel skips those MFMAs.
+      const int Mp = us * U.Cout, PH = us / 2, CG = 32 / PH, Kc = tpp + 1, pl = tpp - 1 - pad / us;
       PConv pc;
-      pc.M = Mp; pc.Mpad = (int)align_up(Mp, 128); pc.Cin = U.Cin; pc.K = 5;
-      pc.w = P.alloc((size_t)5 * U.Cin * pc.Mpad);
+      pc.M = Mp; pc.Mpad = (int)align_up(Mp, 128); pc.Cin = U.Cin; pc.K = Kc;
+      pc.w = P.alloc((size_t)Kc * U.Cin * pc.Mpad);
       pc.bias = P.alloc(Mp);
       pc.has_bias = true;
       const HostTensor& bt = P.t(std::string(p) + ".bias");
       for (int row = 0; row < Mp; ++row) {
         const int grp = row / 64, half = (row % 64) / 32, k = row % 32;
-        const int co = grp * 16 + k / 2, r = 2 * half + (k & 1);
-        const int kr = (r + 6) % 4, sh = (r + 6 - kr) / 4;
+        const int co = grp * CG + k / PH, r = half * PH + k % PH;
+        const int kr = (r + pad) % us, sh = (r + pad - kr) / us;
         arena[pc.bias + row] = bt.data[co];
-        for (int tau = 0; tau < 5; ++tau) {
-          const int j = sh + 2 - tau;
+        for (int tau = 0; tau < Kc; ++tau) {
+          const int j = sh + pl - tau;
           for (int ci = 0; ci < U.Cin; ++ci)
             arena[pc.w + conv_pack_index(tau, ci, row, U.Cin, pc.Mpad)] =
-                (j >= 0 && j < 4) ? w[((size_t)ci * U.Cout + co) * 16 + kr + 4 * j] : 0.f;
+                (j >= 0 && j < tpp) ? w[((size_t)ci * U.Cout + co) * 16 + kr + us * j] : 0.f;
         }
       }
       m->upc[i] = pc;
@@ -768,11 +769,12 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
     float* r = sc.take<float>(n);
     xs = sc.take<float>(n);
     static const int convt_as_conv = [] { const char* e = getenv("MBV_CONVT_AS_CONV"); return e ? atoi(e) : 1; }();
-    if (us == 4 && m->upc[i].M && convt_as_conv) {
+    if (m->upc[i].M && convt_as_conv) {
       ConvArgs a = conv_args(m, m->upc[i], cur, (int64_t)m->ups[i].Cin * L, L, u, (int64_t)ch * Lo, L, B);
-      a.pad_left = 2;
+      a.pad_left = us == 4 ? 2 : 1;
       a.in_slope = kLrelu;
       a.epi = EPI_CONVT;
+      a.convt_u = us;
       launch_conv1d(a, s);
     } else {
       ConvTArgs a{};

@@ -501,21 +501,45 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
       }
     } else if constexpr (EPI == EPI_CONVT) {
       if constexpr (WM == 2) {
-        // lane: column t, rows k (even) and k + 1 of both i-tiles = the 4 output phases of one channel
-        const int Tout = 4 * T;
         float* yb = a.y + (int64_t)b * a.y_bstride;
+        if (a.convt_u == 4) {
+          // lane: column t, rows k (even) and k + 1 of both i-tiles = the 4 output phases of one channel
+          const int Tout = 4 * T;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int k = (r & 3) + 8 * (r >> 2) + 4 * hl;
-          const float bias = __shfl(rowc, k);
-          const int co = (wrow0 >> 6) * 16 + (k >> 1);
+          for (int r = 0; r < 16; r += 2) {
+            const int k = (r & 3) + 8 * (r >> 2) + 4 * hl;
+            const float bias = __shfl(rowc, k);
+            const int co = (wrow0 >> 6) * 16 + (k >> 1);
 #pragma unroll
-          for (int j = 0; j < WN; ++j) {
-            const int t = t0 + wn * 32 * WN + j * 32 + l31;
-            if (t < T) {
-              f32x4 o = {acc[0][j][r] + bias, acc[0][j][r + 1] + bias, acc[1][j][r] + bias,
-                         acc[1][j][r + 1] + bias};
-              *reinterpret_cast<f32x4*>(yb + (int64_t)co * Tout + 4 * (int64_t)t) = o;
+            for (int j = 0; j < WN; ++j) {
+              const int t = t0 + wn * 32 * WN + j * 32 + l31;
+              if (t < T) {
+                f32x4 o = {acc[0][j][r] + bias, acc[0][j][r + 1] + bias, acc[1][j][r] + bias,
+                           acc[1][j][r + 1] + bias};
+                *reinterpret_cast<f32x4*>(yb + (int64_t)co * Tout + 4 * (int64_t)t) = o;
+              }
+            }
+          }
+        } else {
+          // stride 8: registers 4 q .. 4 q + 3 are rows k .. k + 3 = phases 0-3 (i = 0) / 4-7 (i = 1) of one channel
+          const int Tout = 8 * T;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int k = 8 * rg + 4 * hl;
+            const float bias = __shfl(rowc, k);
+            const int co = (wrow0 >> 6) * 8 + (k >> 2);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int t = t0 + wn * 32 * WN + j * 32 + l31;
+              if (t < T) {
+                float* dst = yb + (int64_t)co * Tout + 8 * (int64_t)t;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  f32x4 o = {acc[i][j][4 * rg] + bias, acc[i][j][4 * rg + 1] + bias,
+                             acc[i][j][4 * rg + 2] + bias, acc[i][j][4 * rg + 3] + bias};
+                  *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+                }
+              }
             }
           }
         }

@@ -16,9 +16,10 @@ enum ConvEpilogue : int {
   EPI_GATE = 3,      // rows come in (tanh-tile, sigmoid-tile) pairs: y[c] = tanh(.)*sigmoid(.)
   EPI_RES_SKIP = 4,  // row < split: xio = (xio + v) * mask ; else skip[row-split] (+)= v
   EPI_COUPLE = 5,    // y = (y + couple_sign * (acc + bias) * mask) * mask   (sign -1: reverse flow)
-  EPI_CONVT = 6,     // ConvTranspose1d(k16, s4, p6) as a 5-tap conv over its 4 output phases: rows come
-                     // in groups of 64 = 16 channels x (phases 0,1 | phases 2,3); tap 0 is all-zero for
-                     // the second half, tap 4 for the first (their MFMAs are skipped); y[co, 4t .. 4t+3]
+  EPI_CONVT = 6,     // ConvTranspose1d(k16, stride U = 4 | 8, p (16-U)/2) as a (16/U + 1)-tap conv over its U
+                     // output phases: rows come in groups of 64 = 64/U channels x (first U/2 phases | last
+                     // U/2 phases); tap 0 is all-zero for the second half, the last tap for the first
+                     // (their MFMAs are skipped); a lane stores y[co, U t .. U t + U - 1]
 };
 
 struct ConvArgs {
@@ -67,6 +68,7 @@ struct ConvArgs {
   size_t ws_floats;
   unsigned* counters;
   int n_counters;
+  int convt_u;             // EPI_CONVT: upsampling stride (4 or 8)
   int splitk;              // 1: split-K allowed for this launch (mbv_set_option "splitk" / MBV_CONV_SPLITK)
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
