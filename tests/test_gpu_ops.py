@@ -206,3 +206,56 @@ def test_c_abi_error_paths(net):
         net.istft_finalize(torch.zeros(1, 4, 9, 18, device="cuda"), torch.zeros(1, 4, 9, 17, device="cuda"))
     with pytest.raises(_capi.MbvError, match="16 n \\+ 1"):
         net.istft_finalize(torch.zeros(1, 4, 9, 18, device="cuda"), torch.zeros(1, 4, 9, 18, device="cuda"))
+
+
+def test_c_abi_positive_path_with_raw_ctypes():
+    """The path through the C ABI alone — what a maintainer binding `include/mbistft_vits.h` from the
+    reference's own `models.py` would write: create, load every state-dict key,
+    finalize, encode, read max(y_lengths), synthesize — against the `mini_b1` golden from the
+    reference.  No `mb_istft_vits_amd.models` involved; torch only allocates the buffers."""
+    import ctypes as C
+    from helpers import load_fixture, config_for, rms
+    from mb_istft_vits_amd import _capi, synth
+    gold = load_fixture("mini_b1")
+    _, cfg = config_for("ljs_mini_mb_istft_vits", int(gold["n_vocab"]))
+    L = _capi.lib()
+    c = _capi.MbvConfig()
+    c.struct_bytes = C.sizeof(_capi.MbvConfig)
+    c.n_vocab, c.inter_channels, c.hidden_channels = cfg.n_vocab, cfg.inter_channels, cfg.hidden_channels
+    c.filter_channels, c.n_heads, c.n_layers = cfg.filter_channels, cfg.n_heads, cfg.n_layers
+    c.kernel_size, c.upsample_initial_channel, c.spec_channels = cfg.kernel_size, cfg.upsample_initial_channel, cfg.spec_channels
+    for j in range(3):
+        c.resblock_kernel_sizes[j] = cfg.resblock_kernel_sizes[j]
+        for q, d in enumerate(cfg.resblock_dilation_sizes[j]):
+            c.resblock_dilations[j][q] = d
+    c.resblock_type, c.n_speakers, c.gin_channels, c.decoder, c.device, c.use_sdp = 1, 0, 0, 0, 0, 0
+    h = C.c_void_p()
+    assert L.mbv_create(C.byref(c), C.byref(h)) == 0, L.mbv_last_error(None)
+    try:
+        for k, v in synth.make_state_dict(cfg, int(gold["weight_seed"])).items():
+            a = np.ascontiguousarray(v, np.float32)
+            assert L.mbv_load_weight(h, k.encode(), a.ctypes.data_as(C.c_void_p),
+                                     (C.c_int64 * a.ndim)(*a.shape), a.ndim) == 0, L.mbv_last_error(h)
+        assert L.mbv_missing_weights(h, None, 0) == 0
+        assert L.mbv_finalize_weights(h, None) == 0, L.mbv_last_error(h)
+        x = torch.from_numpy(gold["x"]).cuda()
+        xl = torch.from_numpy(gold["x_lengths"]).cuda()
+        B, T = x.shape
+        ylen = torch.empty(B, dtype=torch.int64, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert L.mbv_encode(h, p(x), p(xl), None, B, T, C.c_float(1.0), None, C.c_float(1.0), p(ylen), st) == 0
+        Tp = int(ylen.max())                                   # the one host sync of the path
+        o = torch.empty(B, 1, 256 * Tp, device="cuda")
+        z = torch.empty(B, cfg.inter_channels, Tp, device="cuda")
+        out = _capi.MbvOutputs()
+        out.o, out.z = o.data_ptr(), z.data_ptr()              # every other output skipped (NULL)
+        assert L.mbv_synthesize(h, Tp, None, C.c_float(0.0), 0, C.byref(out), st) == 0, L.mbv_last_error(h)
+        torch.cuda.synchronize()
+        assert np.array_equal(ylen.cpu().numpy(), gold["y_mask"].sum((1, 2)).astype(np.int64))
+        assert rms(o.cpu().numpy() - gold["o"]) < 1e-4
+        assert rms(z.cpu().numpy() - gold["z"]) <= 5e-5 * rms(gold["z"])
+        t5 = (C.c_float * 5)()
+        assert L.mbv_stage_times_ms(h, C.byref(t5)) == 0 and all(v >= 0 for v in t5)
+    finally:
+        L.mbv_destroy(h)
