@@ -143,7 +143,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  // 256-thread shapes: wave index made provably uniform, so the nact / nj tests become scalar
+  // branches (in the 512-thread shape the extra SGPR pressure makes the kernel spill instead)
+  const int wave = NWN == 2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int hl = lane >> 5, l31 = lane & 31;
 
@@ -376,30 +378,43 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           }
           /* EPI_CONVT: the i-tile whose weights are structurally zero at this tap (none: -1) */ \
 #define MBV_SKIP(ST) (EPI == EPI_CONVT ? ((ST) / G == 0 ? 1 : ((ST) / G == a.K - 1 ? 0 : -1)) : -1)
-#define MBV_MMA(AV, BV, SK)                                                        \
+#define MBV_MMA(AV, BV, SK, ALLJ)                                                  \
           {                                                                        \
             const int sk_ = (SK);                                                  \
             _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                       \
               _Pragma("unroll") for (int i = 0; i < WM; ++i)                       \
                 _Pragma("unroll") for (int j = 0; j < WN; ++j)                     \
-                  if (j < nj && i != sk_)                                          \
+                  if (((ALLJ) || j < nj) && (EPI != EPI_CONVT || i != sk_))        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[i][s4], BV[j][s4], acc[i][j], 0, 0, 0); \
           }
           // operands double-buffered one step ahead; sched_barrier keeps hipcc from sinking the
           // prefetch back behind the MFMAs
-          MBV_LOAD_AB(0, a0, b0);
-          int st = 0;
-          for (; st + 1 < nsteps; st += 2) {
-            MBV_LOAD_AB(st + 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            MBV_MMA(a0, b0, MBV_SKIP(st));
-            __builtin_amdgcn_sched_barrier(0);
-            MBV_LOAD_AB(st + 2, a0, b0);   // the last pass reads one step past the slab (padded, unused)
-            __builtin_amdgcn_sched_barrier(0);
-            MBV_MMA(a1, b1, MBV_SKIP(st + 1));
-            __builtin_amdgcn_sched_barrier(0);
+          // interior patches (every column tile inside the sequence) run a loop without any test
+          // between the MFMAs; edge patches the predicated one
+#define MBV_STEP_LOOP(ALLJ)                                                        \
+          {                                                                        \
+            MBV_LOAD_AB(0, a0, b0);                                                \
+            int st = 0;                                                            \
+            for (; st + 1 < nsteps; st += 2) {                                     \
+              MBV_LOAD_AB(st + 1, a1, b1);                                         \
+              __builtin_amdgcn_sched_barrier(0);                                   \
+              MBV_MMA(a0, b0, MBV_SKIP(st), ALLJ);                                 \
+              __builtin_amdgcn_sched_barrier(0);                                   \
+              MBV_LOAD_AB(st + 2, a0, b0); /* last pass: one step past the slab (padded, unused) */ \
+              __builtin_amdgcn_sched_barrier(0);                                   \
+              MBV_MMA(a1, b1, MBV_SKIP(st + 1), ALLJ);                             \
+              __builtin_amdgcn_sched_barrier(0);                                   \
+            }                                                                      \
+            if (st < nsteps) { MBV_MMA(a0, b0, MBV_SKIP(st), ALLJ); } /* odd step count */ \
           }
-          if (st < nsteps) { MBV_MMA(a0, b0, MBV_SKIP(st)); }  // odd step count
+          // (256-thread shapes only: in the 512-thread shape the second loop body costs ~100 registers
+          // of live ranges and the kernel spills)
+          if constexpr (NWN == 2) {
+            if (nj == WN) MBV_STEP_LOOP(true) else MBV_STEP_LOOP(false)
+          } else {
+            MBV_STEP_LOOP(false)
+          }
+#undef MBV_STEP_LOOP
 #undef MBV_LOAD_AB
 #undef MBV_MMA
 #undef MBV_SKIP
