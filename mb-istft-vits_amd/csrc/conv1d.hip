@@ -412,7 +412,11 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           if constexpr (NWN == 2) {
             if (nj == WN) MBV_STEP_LOOP(true) else MBV_STEP_LOOP(false)
           } else {
-            MBV_STEP_LOOP(false)
+            // 512-thread shape: no column test at all — columns past the end of the sequence are
+            // staged as zeros and never stored, so the few MFMAs they cost on the last tile of a row
+            // buy a loop without exec-mask juggling around every MFMA
+            static_assert(NWN == 4, "");
+            if (nj > 0) MBV_STEP_LOOP(true)
           }
 #undef MBV_STEP_LOOP
 #undef MBV_LOAD_AB
