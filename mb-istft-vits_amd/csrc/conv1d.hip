@@ -86,6 +86,39 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
             for (int j = 0; j < WN; ++j) acc[i][j][r] += tmp[r][j];
         }
       }
+    } else if (EPI == EPI_RES_SKIP && full && a.split % 32 == 0) {
+      // a 32-row tile lies wholly on one side of the res / skip split (the split is a channel count)
+      const int64_t col_off = (int64_t)(4 * hl) * a.T + t0 + wn * 32 * WN + l31;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int trow = wrow0 + i * 32;                               // wave-uniform
+        const bool is_x = trow < a.split;
+        const float* base = is_x ? a.y + (int64_t)b * a.y_bstride + (int64_t)trow * a.T
+                                 : a.skip + ((int64_t)b * (a.M - a.split) + (trow - a.split)) * a.T;
+        if (is_x || a.skip_accum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float* q = base + col_off + (int64_t)((r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j][r] = q[j * 32];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j][r] = 0.f;
+        }
+      }
+    } else if (EPI == EPI_COUPLE && full) {
+      const float* py = a.y + (int64_t)b * a.y_bstride + lane_off;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* q = py + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j][r] = a.couple_sign * q[j * 32];
+        }
     } else {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -578,6 +611,44 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
             if constexpr (EPI == EPI_STORE) { if (a.relu) v = fmaxf(v, 0.f); }
             if constexpr (EPI == EPI_RESID_ACC) v *= a.out_scale;
             q[j * 32] = v;
+          }
+        }
+    } else if (EPI == EPI_RES_SKIP && full && a.split % 32 == 0) {
+      const int64_t col_off = (int64_t)(4 * hl) * T + t0 + wn * 32 * WN + l31;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int trow = wrow0 + i * 32;
+        const bool is_x = trow < a.split;
+        float* base = is_x ? a.y + (int64_t)b * a.y_bstride + (int64_t)trow * T
+                           : a.skip + ((int64_t)b * (a.M - a.split) + (trow - a.split)) * T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = (r & 3) + 8 * (r >> 2);
+          const float bias = __shfl(rowc, i * 32 + k0 + 4 * hl);
+          float* q = base + col_off + (int64_t)k0 * T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
+            float v = acc[i][j][r] + bias;
+            if (is_x) v = t < len_out ? v : 0.f;                   // xio = (xio + rs) * mask
+            q[j * 32] = v;
+          }
+        }
+      }
+    } else if (EPI == EPI_COUPLE && full) {
+      float* py = a.y + (int64_t)b * a.y_bstride + lane_off;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k0 = i * 32 + (r & 3) + 8 * (r >> 2);
+          const float bias = __shfl(rowc, k0 + 4 * hl);
+          float* q = py + (int64_t)k0 * T;
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int t = t0 + wn * 32 * WN + j * 32 + l31;
+            const float v = a.couple_sign * (acc[i][j][r] + bias);
+            q[j * 32] = t < len_out ? v : 0.f;
           }
         }
     } else {
