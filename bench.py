@@ -4,7 +4,13 @@ MI355X path, BASELINE.json configs[1] (ljs_mb_istft_vits, batch 64 per GPU,
 T_text = 200, synthetic LJSpeech-length batch, synthetic checkpoint).
 
   python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` (N > 1) works as typed: when the process was not started by a launcher (no WORLD_SIZE in
+the environment) it starts N ranks itself — `python -m torch.distributed.run --nproc-per-node N
+bench.py …` as a CHILD process, before this process touches a GPU — relays rank 0's JSON line and
+exits with the children's code.  Started under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.  On a box with fewer GPUs than ranks the
+launcher falls back to a REHEARSAL (ranks share devices, `gloo` instead of RCCL) and the JSON says so.
 
 A step = one full `infer` (text encoder .. waveform, all 8 reference outputs
 materialised) over one batch of 64 utterances per GPU; with N > 1 the global
@@ -13,21 +19,25 @@ the waveforms are all-gathered (RCCL) inside the timed region.  `value` counts
 VALID output samples (256 * sum y_lengths) of all ranks per second.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s float4 copy)
 FP32_PEAK_TFLOPS = 157.3     # fp32 MFMA == fp32 vector peak
 ISTFT_BYTES_PER_FRAME = 72 * 16 * 4 + 256 * 4           # 5632 B: SURVEY §8d (waveform-only mode)
 ISTFT_BYTES_PER_FRAME_ALL = ISTFT_BYTES_PER_FRAME + 2 * 36 * 16 * 4 + 1024   # + spec, phase, o_mb (MB)
+# BASELINE.json "configs": which entry a (config, per-GPU batch, n_gpus) combination is
+BASELINE_CONFIGS = {("ljs_mini_mb_istft_vits", 1, 1): 0, ("ljs_mb_istft_vits", 64, 1): 1,
+                    ("ljs_ms_istft_vits", 64, 1): 2, ("ljs_mb_istft_vits", 64, 8): 3,
+                    ("uudb_ms_istft_vits_ms", 32, 8): 4}
 
 
 def decoder_flops_per_frame(cfg):
@@ -44,7 +54,44 @@ def decoder_flops_per_frame(cfg):
     return 2.0 * mac
 
 
-def main():
+def flow_flops_per_frame(cfg):
+    """2 * MAC of the four reverse coupling layers per z-frame (14.2 MFLOP)."""
+    H, I = cfg.hidden_channels, cfg.inter_channels
+    per_flow = (I // 2) * H + 4 * (2 * H * H * 5) + 3 * (2 * H * H) + H * H + H * (I // 2)
+    return 2.0 * 4 * per_flow
+
+
+def encoder_flops_per_token(cfg, T):
+    """2 * MAC of the text encoder per token at padded length T (13.5 MFLOP at T=200)."""
+    H, Fc, I = cfg.hidden_channels, cfg.filter_channels, cfg.inter_channels
+    per_layer = 4 * H * H + 2 * H * T + 2 * cfg.kernel_size * H * Fc
+    return 2.0 * (cfg.n_layers * per_layer + 2 * I * H)
+
+
+def kernel_source_sha(name):
+    with open(os.path.join(ROOT, "mb-istft-vits_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def physical_cores():
+    try:
+        pairs = set()
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -54,28 +101,61 @@ def main():
     ap.add_argument("--config", default="ljs_mb_istft_vits")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def self_launch(args):
+    """N > 1 without a launcher: start the ranks as children of THIS process, which has not made a
+    single GPU call (`torch.cuda.device_count()` does not initialise the GPU on this image; nothing
+    else below touches it), relay their output and return their exit code."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < 1:
+        print("bench.py needs an MI355X (no CPU fallback exists for the product path)", file=sys.stderr)
+        return 1
+    if n_dev < args.gpus:
+        # not a scaling measurement: the ranks share the devices that exist and talk over gloo
+        print("bench.py: %d GPU(s) visible for --gpus %d -> REHEARSAL (ranks share devices, gloo backend); "
+              "the JSON line is marked \"rehearsal\": true" % (n_dev, args.gpus), file=sys.stderr)
+        env["MBV_BENCH_SHARE_DEVICES"] = str(n_dev)
+        env.setdefault("MBV_BENCH_BACKEND", "gloo")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" %
-                             (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    if os.environ.get("MBV_BENCH_ONE_DEVICE"):       # rehearsal: all ranks on cuda:0 (with gloo)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    share = int(os.environ.get("MBV_BENCH_SHARE_DEVICES", "0") or 0)
+    if os.environ.get("MBV_BENCH_ONE_DEVICE"):       # older spelling of the rehearsal switch
+        share = 1
+    dev_index = local_rank % share if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     from mb_istft_vits_amd import models, utils, synth, dist as mdist, spec as mspec
     # MBV_BENCH_FORCE_DIST=1: take the sharded (RCCL) code path even with one rank — the rehearsal a
     # one-GPU box allows for broadcast / all-reduce / all-gather on the real backend
     dist_on = world > 1 or bool(os.environ.get("MBV_BENCH_FORCE_DIST"))
+    backend = None
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -107,11 +187,12 @@ def main():
     x, xl = torch.from_numpy(x_np).to(dev), torch.from_numpy(xl_np).to(dev)
     sid = torch.from_numpy(sid_np).to(dev) if sid_np is not None else None
 
-    def step():
+    def step(outputs=None):
+        # outputs=None: every shard / the single GPU materialises all 8 tensors of the reference tuple
         if dist_on:
-            o, ylen = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1)
+            o, ylen = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1, outputs=outputs)
         else:
-            (o, *_), ylen = net.infer_with_lengths(x, xl, sid, noise_scale=0, length_scale=1)
+            (o, *_), ylen = net.infer_with_lengths(x, xl, sid, noise_scale=0, length_scale=1, outputs=outputs)
         return o, ylen
 
     def sync():
@@ -139,45 +220,98 @@ def main():
     Tp = o.shape[-1] // cfg.samples_per_frame
     value = valid_samples * args.steps / elapsed
 
+    # secondary: the same job when the caller only takes the waveform (`outputs=("o",)`, what
+    # tts_vits.py:134-137 uses of the tuple) — not the headline
+    for _ in range(2):
+        step(("o",))
+    sync()
+    t1 = time.perf_counter()
+    n_wave = max(3, args.steps // 2)
+    for _ in range(n_wave):
+        step(("o",))
+    sync()
+    wave_elapsed = time.perf_counter() - t1
+    if dist_on:
+        t = torch.tensor([wave_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wave_elapsed = float(t.item())
+
+    dist_info = None
+    if dist_on:
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d: cuda:%d %s" % (rank, dev_index, torch.cuda.get_device_name(dev)))
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": names,
+                     "rehearsal": bool(share), "collectives_per_step":
+                     "1 all_reduce(MAX) of [T', status] (2 x int64) + all_gather(waveform rows) + all_gather(y_lengths)"}
+
     stage_ms = None
     if rank == 0:
         out = net.infer(x[:B], xl[:B], sid[:B] if sid is not None else None, noise_scale=0, length_scale=1)
         stage_ms = {k: round(v * 1e3, 3) for k, v in dict(out[7]).items()}
 
-    # ---- roofline of the fused iSTFT+PQMF launch, waveform-only mode ----
-    roof, roof_conv = None, None
-    if rank == 0:
+    # ---- roofline of the fused iSTFT+PQMF launch ------------------------
+    roof, roof_conv, roof_other = None, None, None
+    if rank == 0 and cfg.decoder != mspec.DEC_SB:
         from mb_istft_vits_amd.benchutil import istft_waveform_only_ms
-        wave_ms = istft_waveform_only_ms(net, B, Tp, iters=50)
         frames = B * Tp
-        ach = ISTFT_BYTES_PER_FRAME * frames / (wave_ms * 1e-3) / 1e9
-        traffic = None
+        wave_ms = istft_waveform_only_ms(net, B, Tp, iters=50)
+        # the same launch on a working set far past the 256 MiB Infinity Cache: rotate enough
+        # distinct (input, output) buffer sets that nothing is still cached when a set comes round again
+        set_bytes = ISTFT_BYTES_PER_FRAME * frames
+        nsets = max(3, int(np.ceil(3.0 * 256 * 2 ** 20 / set_bytes)))
+        cold_ms = istft_waveform_only_ms(net, B, Tp, iters=50, rotate=nsets)
+        all_ms = float(np.mean(istft_ms))
+        ach = set_bytes / (wave_ms * 1e-3) / 1e9
+        ach_cold = set_bytes / (cold_ms * 1e-3) / 1e9
+        ach_all = ISTFT_BYTES_PER_FRAME_ALL * frames / (all_ms * 1e-3) / 1e9
+        # HBM traffic from PMC counters: a separate rocprofv3 --pmc pass (it cannot run inside this
+        # process); only quoted when it was taken for THIS kernel source and THIS launch shape
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "istft_pqmf_pmc.json")
         if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            if (pj.get("B"), pj.get("Tp")) == (B, Tp) and pj.get("kernel_source_sha16") == kernel_source_sha("istft_pqmf.hip"):
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel source at this shape (%s); not this run" % pj.get("profile", "profiles/")
         roof = {"kernel": "istft_pqmf_kernel<480,512> (waveform-only)", "bound": "hbm",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": ISTFT_BYTES_PER_FRAME * frames, "ms_per_launch": round(wave_ms, 4),
-                "all_outputs": {"ms_per_launch": round(float(np.mean(istft_ms)), 4),
-                                "achieved": round(ISTFT_BYTES_PER_FRAME_ALL * frames /
-                                                  (float(np.mean(istft_ms)) * 1e-3) / 1e9, 1),
-                                "unit": "GB/s"}}
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": set_bytes, "ms_per_launch": round(wave_ms, 4),
+                "note": "working set %.0f MB < 256 MiB Infinity Cache: as in the pipeline, where x_post was just written by the preceding conv" % (set_bytes / 1e6),
+                "past_cache": {"what": "same launch, %d rotating buffer sets (%.0f MB working set)" % (nsets, nsets * set_bytes / 1e6),
+                               "ms_per_launch": round(cold_ms, 4), "achieved": round(ach_cold, 1),
+                               "frac": round(ach_cold / HBM_PEAK_GBS, 4), "unit": "GB/s"},
+                "all_outputs": {"what": "the launch `infer` issues by default (spec, phase, o_mb written too: %d B/frame)" % ISTFT_BYTES_PER_FRAME_ALL,
+                                "ms_per_launch": round(all_ms, 4), "achieved": round(ach_all, 1),
+                                "frac": round(ach_all / HBM_PEAK_GBS, 4), "unit": "GB/s"}}
+    if rank == 0:
+        frames = B * Tp
         fl = decoder_flops_per_frame(cfg) * frames
         cm = float(np.mean(conv_ms))
-        roof_conv = {"kernel": "decoder conv stack (conv1d_mfma/convt4_mfma, fp32 MFMA)", "bound": "mfma",
+        roof_conv = {"kernel": "decoder conv stack (conv1d_mfma, fp32 MFMA)", "bound": "mfma",
                      "achieved": round(fl / (cm * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(fl / (cm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                      "ms_per_step": round(cm, 3), "flop_per_step": fl}
         pmc_conv = os.path.join(ROOT, "profiles", "conv_mfma_pmc.json")
         if os.path.isfile(pmc_conv):             # matrix-pipe busy share from a separate --pmc pass
-            roof_conv["mfma_util_percent_pmc"] = json.load(open(pmc_conv)).get("mfma_util_percent")
+            pj = json.load(open(pmc_conv))
+            if pj.get("kernel_source_sha16") == kernel_source_sha("conv1d.hip"):
+                roof_conv["mfma_util_percent_pmc"] = pj.get("mfma_util_percent")
+                roof_conv["mfma_util_source"] = pj.get("source")
+        if stage_ms:
+            fe = encoder_flops_per_token(cfg, args.t_text) * B * args.t_text
+            ff = flow_flops_per_frame(cfg) * frames
+            roof_other = {
+                "text_encoder": {"tflops": round(fe / (stage_ms["text_encoder"] * 1e-3) / 1e12, 1),
+                                 "frac": round(fe / (stage_ms["text_encoder"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 3)},
+                "flow": {"tflops": round(ff / (stage_ms["flow"] * 1e-3) / 1e12, 1),
+                         "frac": round(ff / (stage_ms["flow"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 3)}}
 
     # ---- CPU baseline: the oracle ("port") on this box's host cores ------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_infer
-        nb = 8
+        nb = min(8, B)
         W = ref_infer.Weights(sd_np)
         sid8 = sid_np[:nb] if sid_np is not None else None
 
@@ -211,6 +345,8 @@ def main():
         except OSError:
             pass
         cpu = {"value": round(cpu_samples / t_best, 1), "unit": "samples/s", "cores": best, "kind": "port",
+               "cores_meaning": "threads used (torch.set_num_threads) at the fastest of the thread counts tried",
+               "physical_cores": physical_cores(), "logical_cpus": os.cpu_count(),
                "sample": "first %d utterances of the batch-%d workload; oracle (PyTorch-CPU fp32 restatement "
                          "of the reference) infer, 1 warm-up (B=2) + median of 3 timed calls per thread "
                          "count; value = the fastest thread count" % (nb, B),
@@ -219,6 +355,9 @@ def main():
                "cpu_model": cpu_model, "torch": torch.__version__}
 
     if rank == 0:
+        idx = BASELINE_CONFIGS.get((args.config, B, world))
+        label = ("configs[%d]" % idx) if idx is not None and args.t_text == 200 and not args.ragged else \
+            "not a BASELINE.json config"
         line = {
             "metric": "audio samples/sec (%g kHz), MB-iSTFT-VITS infer, batch %d per GPU" % (sr / 1000.0, B),
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -226,17 +365,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (token ids uniform, T_text=%d%s; synthetic checkpoint seed 1234)" %
                     (args.t_text, " ragged" if args.ragged else ""),
-            "config": {"workload": "configs[1]: %s, batch %d per GPU, infer(noise_scale=0, length_scale=1)"
-                                   % (args.config, B),
+            "config": {"workload": "%s: %s, batch %d per GPU, infer(noise_scale=0, length_scale=1), all 8 outputs"
+                                   % (label, args.config, B),
                        "global_batch": B * world, "t_text": args.t_text, "t_frames_max": Tp,
                        "valid_samples_per_step": valid_samples, "sampling_rate": sr,
                        "parallelism": "utterance-sharded dp%d" % world},
             "rtf": round((elapsed / args.steps) / (valid_samples / sr), 7),
-            "stage_ms": stage_ms, "roofline": roof, "roofline_conv": roof_conv, "cpu_baseline": cpu,
+            "waveform_only": {"what": "same job with infer(outputs=('o',)) (a caller that takes [0] only)",
+                              "value": round(valid_samples * n_wave / wave_elapsed, 1),
+                              "ms_per_step": round(wave_elapsed / n_wave * 1e3, 3)},
+            "dist": dist_info,
+            "stage_ms": stage_ms, "roofline": roof, "roofline_conv": roof_conv, "roofline_other": roof_other,
+            "cpu_baseline": cpu,
         }
         if cpu:
             line["gpu_over_cpu_rtf"] = round(cpu["rtf"] / line["rtf"], 1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist_on:
         dist.destroy_process_group()
 

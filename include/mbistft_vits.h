@@ -148,7 +148,11 @@ int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, v
  *                  10.3 -> 6.5 ms).  Deterministic, within fp32 rounding of the default; a row is
  *                  then no longer bitwise independent of the batch it is computed in.  Default 0
  *                  (or the MBV_CONV_SPLITK environment variable at mbv_create time).
- *   "istft_exact"  1: libm transcendentals in the fused iSTFT kernel (default 0 / MBV_ISTFT_EXACT). */
+ *   "istft_exact"  1: libm transcendentals in the fused iSTFT kernel (default 0 / MBV_ISTFT_EXACT).
+ *   "xpost_chunk_bytes"  the fused iSTFT kernels address their input with 32-bit byte offsets, so a
+ *                  batch whose x_post ([B, 72, F] fp32) would reach 2 GiB runs subband_conv_post +
+ *                  iSTFT in sub-batches (same T', bitwise the unsplit result).  This option lowers
+ *                  the cap (bytes; 0 = 2 GiB - 1) — tests use it to take the split path at small sizes. */
 int mbv_set_option(mbv_model *m, const char *name, int value);
 
 /* ---- stage timers -----------------------------------------------------------

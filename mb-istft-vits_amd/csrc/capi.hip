@@ -91,6 +91,7 @@ struct mbv_model {
   int xpost_F = 1;             // frames per row of the last x_post stage tensor
   int xpost_rows = 72;         // 72 (4 bands x 18) or 18 (single band)
   int exact_math = 0;          // MBV_ISTFT_EXACT=1: libm transcendentals in the iSTFT kernel
+  int64_t xpost_chunk_bytes = 0;   // option "xpost_chunk_bytes": sub-batch cap of conv_post + iSTFT (0: 2 GiB - 1)
 
   // state of the last encode
   int B = 0, T = 0;
@@ -119,6 +120,23 @@ struct mbv_model {
   } while (0)
 
 namespace {
+
+// Every entry point runs on the model's device and hands the caller's current device back on
+// every exit path (a process may host models on several GPUs; hipSetDevice is per host thread).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DEVICE_GUARD(m)                                                          \
+  DeviceGuard dev_guard_((m)->cfg.device);                                       \
+  if (!dev_guard_.ok) return (m)->fail("hipSetDevice(%d) failed", (m)->cfg.device)
 
 // ------------------------------------------------------------------ key table
 void add_key(mbv_model* m, const std::string& k, std::initializer_list<int64_t> shape) {
@@ -848,36 +866,54 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   const int Fr = L + 1;
   const int chl = C0 >> 2;
   const int prow = sb ? 18 : 72;
-  if ((int64_t)B * prow * Fr * 4 >= (1LL << 31))
-    return m->fail("batch x frames too large for one launch (x_post must stay below 2 GiB): split the batch");
-  float* xpost = sc.take<float>((size_t)B * prow * Fr);
-  {
-    ConvArgs a = conv_args(m, m->conv_post, cur, (int64_t)chl * L, L, xpost, (int64_t)prow * Fr, Fr, B);
-    a.in_slope = 0.01f;                              // F.leaky_relu default slope (models.py:363)
-    a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
-    launch_conv1d(a, s);
-  }
-  m->stages["x_post"] = {xpost, (int64_t)B * prow * Fr};
-  m->xpost_F = Fr;
-  m->xpost_rows = prow;
+  // The fused iSTFT kernels address x_post with 32-bit byte offsets: a batch whose x_post would
+  // reach 2 GiB runs conv_post + iSTFT in sub-batches (same T', same kernels, per-utterance
+  // arithmetic unchanged: results are bitwise those of an unsplit launch).
+  const int64_t utt_bytes = (int64_t)prow * Fr * 4;
+  int64_t cap_bytes = (1LL << 31) - 1;
+  if (m->xpost_chunk_bytes > 0 && m->xpost_chunk_bytes < cap_bytes) cap_bytes = m->xpost_chunk_bytes;
+  if (utt_bytes > (1LL << 31) - 1)
+    return m->fail("utterance too long for one launch: %d frames (x_post of ONE utterance must stay below 2 GiB)", Td);
+  int Bc = (int)(cap_bytes / utt_bytes);
+  if (Bc < 1) Bc = 1;
+  if (Bc > B) Bc = B;
+  float* xpost = sc.take<float>((size_t)Bc * prow * Fr);
   float* o = outs ? outs->o : nullptr;
   float* otmp = nullptr;
   if (!o) { otmp = sc.take<float>((size_t)B * 256 * Td); o = otmp; }
-  HIPCHK(m, hipEventRecord(m->evk[1], s));
-  if (sb) {
-    IstftSbArgs ia{};
-    ia.x_post = xpost; ia.o = o; ia.spec = outs ? outs->spec : nullptr; ia.phase = outs ? outs->phase : nullptr;
-    ia.B = B; ia.F = Fr; ia.exact_math = m->exact_math; ia.prescaled = 1;
-    launch_istft_single(ia, s);
-  } else {
-    IstftArgs ia{};
-    ia.x_post = xpost; ia.filt = m->W(m->filt.off); ia.o = o;
-    ia.o_mb = outs ? outs->o_mb : nullptr; ia.spec = outs ? outs->spec : nullptr;
-    ia.phase = outs ? outs->phase : nullptr;
-    ia.B = B; ia.Tp = Td; ia.multistream = c.decoder == MBV_DEC_MULTISTREAM;
-    ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
-    launch_istft_pqmf(ia, s);
+  const int64_t M4 = (int64_t)(sb ? 4 : 256) * (sb ? (Fr - 1) : Td);          // waveform samples per utterance
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+    const int nb = B - b0 < Bc ? B - b0 : Bc;
+    {
+      ConvArgs a = conv_args(m, m->conv_post, cur + (size_t)b0 * chl * L, (int64_t)chl * L, L, xpost,
+                             (int64_t)prow * Fr, Fr, nb);
+      a.in_slope = 0.01f;                              // F.leaky_relu default slope (models.py:363)
+      a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
+      launch_conv1d(a, s);
+    }
+    if (b0 == 0) HIPCHK(m, hipEventRecord(m->evk[1], s));
+    if (sb) {
+      IstftSbArgs ia{};
+      ia.x_post = xpost; ia.o = o + (size_t)b0 * M4;
+      ia.spec = outs && outs->spec ? outs->spec + (size_t)b0 * 9 * Fr : nullptr;
+      ia.phase = outs && outs->phase ? outs->phase + (size_t)b0 * 9 * Fr : nullptr;
+      ia.B = nb; ia.F = Fr; ia.exact_math = m->exact_math; ia.prescaled = 1;
+      launch_istft_single(ia, s);
+    } else {
+      IstftArgs ia{};
+      const bool ms = c.decoder == MBV_DEC_MULTISTREAM;
+      ia.x_post = xpost; ia.filt = m->W(m->filt.off); ia.o = o + (size_t)b0 * M4;
+      ia.o_mb = outs && outs->o_mb ? outs->o_mb + (size_t)b0 * (ms ? 1024 : 256) * Td : nullptr;
+      ia.spec = outs && outs->spec ? outs->spec + (size_t)b0 * 36 * Fr : nullptr;
+      ia.phase = outs && outs->phase ? outs->phase + (size_t)b0 * 36 * Fr : nullptr;
+      ia.B = nb; ia.Tp = Td; ia.multistream = ms;
+      ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
+      launch_istft_pqmf(ia, s);
+    }
   }
+  if (Bc == B) m->stages["x_post"] = {xpost, (int64_t)B * prow * Fr};     // (a split run keeps only its last chunk)
+  m->xpost_F = Fr;
+  m->xpost_rows = prow;
   HIPCHK(m, hipEventRecord(m->evk[2], s));
   m->evk_set = true;
   return 0;
@@ -991,7 +1027,8 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return bad("no HIP device visible: this library has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev) return bad("device ordinal out of range");
-  if (hipSetDevice(cfg->device) != hipSuccess) return bad("hipSetDevice failed");
+  DeviceGuard dev_guard_(cfg->device);
+  if (!dev_guard_.ok) return bad("hipSetDevice failed");
   mbv_model* m = new (std::nothrow) mbv_model();
   if (!m) return bad("out of host memory");
   m->cfg = *cfg;
@@ -1025,12 +1062,13 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!name) return m->fail("mbv_set_option: name is NULL");
   if (!strcmp(name, "splitk")) { m->splitk = value != 0; return 0; }
   if (!strcmp(name, "istft_exact")) { m->exact_math = value != 0; return 0; }
-  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact)", name);
+  if (!strcmp(name, "xpost_chunk_bytes")) { m->xpost_chunk_bytes = value > 0 ? value : 0; return 0; }
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, xpost_chunk_bytes)", name);
 }
 
 void mbv_destroy(mbv_model* m) {
   if (!m) return;
-  (void)hipSetDevice(m->cfg.device);
+  DeviceGuard dev_guard_(m->cfg.device);
   if (m->darena) (void)hipFree(m->darena);
   if (m->conv_ws) (void)hipFree(m->conv_ws);
   if (m->conv_cnt) (void)hipFree(m->conv_cnt);
@@ -1077,7 +1115,7 @@ int mbv_missing_weights(mbv_model* m, char* buf, size_t cap) {
 
 int mbv_finalize_weights(mbv_model* m, void* stream) {
   if (!m) return 1;
-  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DEVICE_GUARD(m);
   return do_finalize(m, (hipStream_t)stream);
 }
 
@@ -1085,7 +1123,7 @@ int mbv_speaker_embedding(mbv_model* m, const int64_t* sid, int B, float* out, v
   if (!m) return 1;
   if (!m->finalized) return m->fail("weights not finalized");
   if (!m->emb_g.present) return m->fail("model has no speaker embedding (n_speakers <= 1)");
-  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DEVICE_GUARD(m);
   launch_gather_rows(m->W(m->emb_g.off), sid, out, B, m->cfg.gin_channels, m->cfg.n_speakers, nullptr,
                      (hipStream_t)stream);
   HIPCHK(m, hipGetLastError());
@@ -1117,7 +1155,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   const mbv_config& c = m->cfg;
   if (c.n_speakers > 0 && !sid) return m->fail("sid is required when n_speakers > 0 (models.py:704-705)");
   if (c.n_speakers > 0 && !m->emb_g.present) return m->fail("n_speakers == 1: the reference has no emb_g either");
-  HIPCHK(m, hipSetDevice(c.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels, gin = c.gin_channels;
   const size_t BT = (size_t)B * T;
@@ -1250,7 +1288,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   if (!m->encoded) return m->fail("mbv_synthesize without a preceding mbv_encode");
   if (t_frames <= 0) return m->fail("t_frames must be > 0");
   const mbv_config& c = m->cfg;
-  HIPCHK(m, hipSetDevice(c.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   const int B = m->B, T = m->T, Tp = t_frames, H = c.hidden_channels, I = c.inter_channels;
   const int gin = c.gin_channels;
@@ -1297,7 +1335,7 @@ int mbv_decode(mbv_model* m, const float* z, const float* g, int B, int t_frames
   if (!m->finalized) return m->fail("weights not finalized");
   if (!z || B <= 0 || t_frames <= 0 || !outs) return m->fail("mbv_decode: bad arguments");
   const mbv_config& c = m->cfg;
-  HIPCHK(m, hipSetDevice(c.device));
+  DEVICE_GUARD(m);
   if (ensure(m, &m->scrB, &m->scrB_bytes, decoder_scratch_bytes(c, B, t_frames))) return 1;
   Bump sc{m->scrB, m->scrB_bytes};
   m->stages.clear();
@@ -1310,6 +1348,7 @@ int mbv_decode(mbv_model* m, const float* z, const float* g, int B, int t_frames
 
 int mbv_stage_times_ms(mbv_model* m, float out[5]) {
   if (!m || !out) return 1;
+  DEVICE_GUARD(m);
   if (!m->ev_a || !m->ev_b) return m->fail("no completed encode+synthesize pair to time");
   HIPCHK(m, hipEventSynchronize(m->ev[6]));
   HIPCHK(m, hipEventElapsedTime(&out[0], m->ev[0], m->ev[1]));
@@ -1322,6 +1361,7 @@ int mbv_stage_times_ms(mbv_model* m, float out[5]) {
 
 int mbv_kernel_times_ms(mbv_model* m, float out[2]) {
   if (!m || !out) return 1;
+  DEVICE_GUARD(m);
   if (!m->evk_set) return m->fail("no decoder run to time");
   HIPCHK(m, hipEventSynchronize(m->evk[2]));
   HIPCHK(m, hipEventElapsedTime(&out[0], m->evk[0], m->evk[1]));
@@ -1335,7 +1375,7 @@ int mbv_istft_pqmf(mbv_model* m, const float* x_post, int B, int t_frames, const
   if (!x_post || !o || B <= 0 || t_frames <= 0) return m->fail("mbv_istft_pqmf: bad arguments");
   if ((int64_t)B * 72 * (16 * (int64_t)t_frames + 1) * 4 >= (1LL << 31))
     return m->fail("mbv_istft_pqmf: B * T' too large for one launch (x_post must stay below 2 GiB)");
-  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   float*& d_tab = m->user_tab;
   if (!d_tab) HIPCHK(m, hipMalloc((void**)&d_tab, kFiltTable * sizeof(float)));
@@ -1371,7 +1411,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
     return m->fail("n_speakers have to be larger than 0.");              // models.py:791 assert
   if (!y || !y_lengths || !sid_src || !sid_tgt || !outs || B <= 0 || T <= 0)
     return m->fail("mbv_voice_conversion: bad arguments");
-  HIPCHK(m, hipSetDevice(c.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   const int H = c.hidden_channels, I = c.inter_channels, gin = c.gin_channels, SC = c.spec_channels;
   const auto& Q = m->encq;
@@ -1434,7 +1474,7 @@ int mbv_istft_finalize(mbv_model* m, const float* spec, const float* phase, int 
   if (!m->finalized) return m->fail("weights not finalized");
   if (!spec || !phase || !o || B <= 0 || frames < 2) return m->fail("mbv_istft_finalize: bad arguments");
   const mbv_config& c = m->cfg;
-  HIPCHK(m, hipSetDevice(c.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   if (c.decoder == MBV_DEC_SINGLEBAND) {
     IstftSbArgs a{};
@@ -1459,7 +1499,7 @@ int mbv_pcm16(mbv_model* m, const float* wave, const int64_t* y_lengths, int B, 
               int auto_normalize, int16_t* pcm, void* stream) {
   if (!m) return 1;
   if (!wave || !pcm || B <= 0 || stride <= 0) return m->fail("mbv_pcm16: bad arguments");
-  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DEVICE_GUARD(m);
   if (m->peak_cap < B) {
     if (m->peak_buf) HIPCHK(m, hipFree(m->peak_buf));
     HIPCHK(m, hipMalloc((void**)&m->peak_buf, (size_t)B * sizeof(unsigned)));
@@ -1474,6 +1514,8 @@ int mbv_pcm16(mbv_model* m, const float* wave, const int64_t* y_lengths, int B, 
 int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capacity, void* stream) {
   if (!m || !name) return -1;
   const mbv_config& c = m->cfg;
+  DeviceGuard dev_guard_(c.device);
+  if (!dev_guard_.ok) { m->fail("hipSetDevice(%d) failed", c.device); return -1; }
   std::string n(name);
   const float* src = nullptr;
   int64_t numel = 0;
@@ -1512,7 +1554,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   if (!m) return 1;
   if (Cin % 32) return m->fail("mbv_op_conv1d: Cin must be a multiple of 32");
   if (!conv1d_supported(K, dilation)) return m->fail("mbv_op_conv1d: K <= 11 and (K-1)*dilation <= 72 required");
-  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DEVICE_GUARD(m);
   hipStream_t s = (hipStream_t)stream;
   const int Mpad = (int)align_up(Cout, 128);
   std::vector<float> packed((size_t)K * Cin * Mpad, 0.f);

@@ -302,10 +302,18 @@ void launch_unscale_xpost(const float* src, float* dst, int B, int rows, int F, 
 //   x = clip(x, -1, 1); pcm = int16(x * 32767)   (truncation toward zero, as ndarray.astype)
 // Same fp32 operation order as the NumPy code, so the int16 stream is bit-exact.
 // ---------------------------------------------------------------------------
+// valid samples of row b, clamped to the row: after infer(max_len=k) the waveform rows hold only
+// spf * k samples while y_lengths still counts the untruncated frames (models.py:733-734)
+__device__ __forceinline__ int64_t valid_samples(const int64_t* lens, int b, int spf, int64_t stride) {
+  if (!lens) return stride;
+  const int64_t n = lens[b] * (int64_t)spf;
+  return n < 0 ? 0 : (n > stride ? stride : n);
+}
+
 __global__ void absmax_kernel(const float* x, const int64_t* lens, int64_t stride, int spf,
                               unsigned* peak_bits) {
   const int b = blockIdx.y;
-  const int64_t n = lens ? lens[b] * spf : stride;
+  const int64_t n = valid_samples(lens, b, spf, stride);
   const float* xb = x + (int64_t)b * stride;
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -318,7 +326,7 @@ __global__ void absmax_kernel(const float* x, const int64_t* lens, int64_t strid
 __global__ void pcm16_kernel(const float* x, const int64_t* lens, int64_t stride, int spf,
                              const unsigned* peak_bits, int auto_normalize, short* out) {
   const int b = blockIdx.y;
-  const int64_t n = lens ? lens[b] * spf : stride;
+  const int64_t n = valid_samples(lens, b, spf, stride);
   const float peak = __uint_as_float(peak_bits[b]);
   const bool norm = auto_normalize && peak > 0.01f;
   const float* xb = x + (int64_t)b * stride;

@@ -4,8 +4,9 @@ Utterances are independent, so the path shards by contiguous blocks of the
 batch, one process per GPU.  Collectives (torch.distributed; backend "nccl"
 is RCCL over xGMI on ROCm, "gloo" in the CPU tests):
   * `broadcast_state_dict` — rank 0's checkpoint to every rank, once;
-  * one 1-element all-reduce(MAX) of T' between phase A and phase B, so every
-    shard pads to the GLOBAL T'max: the decoder is unmasked, and an
+  * one 2-element all-reduce(MAX) of [T', error flag] between phase A and phase B
+    (on the device tensor, before its single host read), so every shard pads to
+    the GLOBAL T'max: the decoder is unmasked, and an
     utterance's last ~15 frames depend on the padded length of its batch
     (SURVEY §7 "batch-padding dependence") — with the global pad the gathered
     result is identical to a single-GPU run of the whole batch;
@@ -43,10 +44,13 @@ def broadcast_state_dict(state_dict_or_none, keys_shapes, device, src=0):
     return out
 
 
-def global_max_frames(local_tp, device):
-    t = torch.tensor([int(local_tp)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t.item())
+def reduce_frames_and_status(stat):
+    """In-place all-reduce(MAX) of the device tensor [T'max, error flag] between phase A and phase B:
+    every shard pads to the global T'max, and a shard whose kernels flagged a bad token / length /
+    speaker id makes EVERY rank raise (no rank is left waiting in the all-gather).  The reduce runs
+    on the device tensor before its one host read, so the sharded path keeps the single host sync
+    per call of the unsharded one."""
+    dist.all_reduce(stat, op=dist.ReduceOp.MAX)
 
 
 def gather_waveforms(o_local, ylen_local, shard_sizes):
@@ -70,23 +74,30 @@ def gather_waveforms(o_local, ylen_local, shard_sizes):
 
 
 def sharded_infer(net, x, x_lengths, sid=None, noise_scale=1, length_scale=1, max_len=None,
-                  noise_scale_w=1.):
-    """Every rank passes the SAME full batch (or at least its own block); each
-    synthesises its block and all ranks return the full-batch waveform
-    [B, 1, 256 T'max] and y_lengths [B].  With a StochasticDurationPredictor every rank draws the
-    full-batch duration noise (models.py:94) and uses its block, so that ranks seeded alike
-    reproduce the single-process durations."""
+                  noise_scale_w=1., outputs=("o",)):
+    """Every rank passes the SAME full batch; each synthesises its contiguous block and all ranks
+    return the full-batch waveform [B, 1, 256 T'max] and y_lengths [B].
+
+    By default only the waveform is materialised on each shard (`outputs=("o",)`: this entry
+    returns nothing else); `outputs=None` makes every shard write all eight tensors of the
+    reference tuple, as `infer` does (bench.py times that, so that N = 1 and N > 1 do equal work).
+    Equality with a single-process run of the whole batch: bitwise at noise_scale == 0 (every shard
+    pads to the global T'max).  With noise_scale != 0 each rank draws the prior noise for the WHOLE
+    batch on its device generator and uses its rows, and with a StochasticDurationPredictor each
+    rank draws the full-batch duration noise on the CPU generator (models.py:94) and uses its
+    block — so ranks that are seeded alike (torch.manual_seed) reproduce the single-process draws;
+    ranks seeded differently produce valid but different samples."""
     world, rank = dist.get_world_size(), dist.get_rank()
     B = x.shape[0]
+    if B < world:                                    # same test on every rank, before any collective
+        raise ValueError("batch %d smaller than world size %d" % (B, world))
     sizes = [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]
     lo, hi = shard_bounds(B, world, rank)
-    if hi == lo:
-        raise ValueError("batch %d smaller than world size %d" % (B, world))
-    dev = net._device()
     extra = {}
     if getattr(net.cfg, "use_sdp", False):
         extra = dict(noise_scale_w=noise_scale_w, noise_w=torch.randn(B, 2, x.shape[1])[lo:hi])
     r = net._run(x[lo:hi], x_lengths[lo:hi], sid[lo:hi] if sid is not None else None, noise_scale,
-                 length_scale, max_len, True, frames_hook=lambda tp: global_max_frames(tp, dev), **extra)
+                 length_scale, max_len, True, stat_reduce=reduce_frames_and_status, outputs=outputs,
+                 prior_rows=(lo, hi, B), **extra)
     o_local, ylen_local = r[0], r[8]
     return gather_waveforms(o_local, ylen_local, sizes)

@@ -45,49 +45,62 @@ class _SpeakerEmbedding(_Node):
 
 
 class Timings(dict):
-    """The reference's `timings` dict (seconds per stage, models.py:698-737),
-    filled lazily from HIP events so that `infer` itself never blocks."""
+    """The reference's `timings` dict (seconds per stage, models.py:698-737), filled lazily from
+    HIP events so that `infer` itself never blocks: the first READ of any kind (indexing, get,
+    items/keys/values, iteration, copy, ==, repr, json.dumps, pickle, dict(t)) waits for the call's
+    last kernel and fills in the five stage times.  Until then the stored values are NaN
+    placeholders.  The events belong to the model handle: if a later `infer` on the same model has
+    started before this dict was first read, the values stay NaN (that call's timings replace them)."""
 
     def __init__(self, owner, ticket):
-        super().__init__()
+        super().__init__((k, float("nan")) for k in _STAGES)
         self._owner, self._ticket, self._done = owner, ticket, False
 
     def _resolve(self):
         if not self._done:
             self._done = True
             vals = self._owner._stage_times(self._ticket)
+            self._owner = None
             for k, v in zip(_STAGES, vals):
                 dict.__setitem__(self, k, v)
+        return self
 
     def __getitem__(self, k):
-        self._resolve()
-        return dict.__getitem__(self, k)
+        return dict.__getitem__(self._resolve(), k)
+
+    def get(self, k, default=None):
+        return dict.get(self._resolve(), k, default)
 
     def items(self):
-        self._resolve()
-        return dict.items(self)
+        return dict.items(self._resolve())
 
     def keys(self):
-        self._resolve()
-        return dict.keys(self)
+        return dict.keys(self._resolve())
 
     def values(self):
-        self._resolve()
-        return dict.values(self)
+        return dict.values(self._resolve())
 
     def __iter__(self):
-        self._resolve()
-        return dict.__iter__(self)
+        return dict.__iter__(self._resolve())
 
-    def __len__(self):
-        return len(_STAGES)
+    def copy(self):
+        return dict(dict.items(self._resolve()))
 
-    def __contains__(self, k):
-        return k in _STAGES
+    def __eq__(self, other):
+        if isinstance(other, Timings):
+            other._resolve()
+        return dict.__eq__(self._resolve(), other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (self.copy(),))
 
     def __repr__(self):
-        self._resolve()
-        return dict.__repr__(self)
+        return dict.__repr__(self._resolve())
 
 
 class SynthesizerTrn(nn.Module):
@@ -258,14 +271,34 @@ class SynthesizerTrn(nn.Module):
         return [v * 1e-3 for v in buf]              # reference reports seconds
 
     # ------------------------------------------------------------------ API
+    _OUTPUT_NAMES = ("o", "o_mb", "spec", "phase", "attn", "y_mask", "z", "z_p", "m_p", "logs_p")
+
     @torch.no_grad()
     def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode,
-             frames_hook=None, noise_scale_w=1., noise_w=None):
+             frames_hook=None, noise_scale_w=1., noise_w=None, outputs=None, stat_reduce=None,
+             prior_rows=None):
+        """One encode + synthesize pair.
+          outputs      None = every tensor of the reference's 8-tuple; or a collection of names from
+                       _OUTPUT_NAMES: only those are materialised (the others come back as None and
+                       their stores never happen — `outputs=("o",)` is the waveform-only launch)
+          stat_reduce  sharded runs: called with the device tensor [T'max, error flag] BEFORE the
+                       one host read, reduces it in place over the ranks (all_reduce MAX), so that
+                       every rank pads to the global T'max and every rank raises when any does
+          frames_hook  host-side override of T' (tests: pad a sub-batch like its parent batch)
+          prior_rows   (lo, hi, B_global): draw the prior noise for the whole global batch and use
+                       rows lo:hi (ranks seeded alike then reproduce the single-process draw)"""
         h = self._ensure_handle()
         L = _capi.lib()
         x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
         dev, B, T = x.device, x.shape[0], x.shape[1]
         I = self.cfg.inter_channels
+        if outputs is None:
+            want = set(self._OUTPUT_NAMES)
+        else:
+            want = set(outputs)
+            unknown = want - set(self._OUTPUT_NAMES)
+            if unknown:
+                raise ValueError("unknown output name(s) %s (known: %s)" % (sorted(unknown), ", ".join(self._OUTPUT_NAMES)))
         with torch.cuda.device(dev):
             stream = self._stream()
             y_lengths = torch.empty(B, dtype=torch.int64, device=dev)
@@ -284,58 +317,79 @@ class SynthesizerTrn(nn.Module):
                                         self._ptr(y_lengths), stream),
                         "mbv_encode")
             lo, hi = torch.aminmax(y_lengths)
-            Tp = int(hi.item())                     # the one host sync (commons.py:123)
-            if int(lo.item()) < 0:                  # flagged by the kernels, no extra sync
+            stat = torch.stack((hi, -lo))           # [T'max, > 0 iff an utterance was flagged -1]
+            if stat_reduce is not None:
+                stat_reduce(stat)
+            Tp, flag = (int(v) for v in stat.tolist())      # the one host sync (commons.py:123)
+            if flag > 0:                            # flagged by the kernels, no extra sync
                 raise IndexError("index out of range in self (token id, x_lengths or sid outside the "
                                  "model's tables)")
-            if frames_hook is not None:             # sharded run: pad to the global T' max
+            if frames_hook is not None:
                 Tp = int(frames_hook(Tp))
             # the reference draws randn_like(m_p) even at noise_scale == 0 (models.py:729)
-            noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)
+            if prior_rows is not None and float(noise_scale) != 0.0:
+                r_lo, r_hi, b_all = prior_rows
+                noise = torch.randn(b_all, I, Tp, device=dev, dtype=torch.float32)[r_lo:r_hi].contiguous()
+            else:
+                noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)
             f32 = dict(device=dev, dtype=torch.float32)
             out = _capi.MbvOutputs()
-            attn = torch.empty(B, 1, Tp, T, **f32)
-            y_mask = torch.empty(B, 1, Tp, **f32)
-            z, z_p = torch.empty(B, I, Tp, **f32), torch.empty(B, I, Tp, **f32)
-            m_p, logs_p = torch.empty(B, I, Tp, **f32), torch.empty(B, I, Tp, **f32)
-            out.attn, out.y_mask = attn.data_ptr(), y_mask.data_ptr()
-            out.z, out.z_p, out.m_p, out.logs_p = z.data_ptr(), z_p.data_ptr(), m_p.data_ptr(), logs_p.data_ptr()
-            o = o_mb = spec = phase = None
+            t = {}
+            if "attn" in want:
+                t["attn"] = torch.empty(B, 1, Tp, T, **f32)
+            if "y_mask" in want:
+                t["y_mask"] = torch.empty(B, 1, Tp, **f32)
+            for k in ("z", "z_p", "m_p", "logs_p"):
+                if k in want:
+                    t[k] = torch.empty(B, I, Tp, **f32)
             Td = Tp if max_len is None else max(0, min(Tp, int(max_len)))
-            if decode:
+            if decode and want & {"o", "o_mb", "spec", "phase"}:
                 if Td <= 0:
                     raise ValueError("max_len leaves no frames to decode")
-                o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Td, dev)
-                out.o, out.spec, out.phase = o.data_ptr(), spec.data_ptr(), phase.data_ptr()
-                out.o_mb = o_mb.data_ptr() if o_mb is not None else None
+                o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Td, dev, want)
+                t.update(o=o, o_mb=o_mb, spec=spec, phase=phase)
+            for k, v in t.items():
+                if v is not None:
+                    setattr(out, k, v.data_ptr())
             self._ticket += 1
             _capi.check(h, L.mbv_synthesize(h, Tp, self._ptr(noise), float(noise_scale),
                                             int(Td if max_len is not None else 0), C.byref(out), stream),
                         "mbv_synthesize")
         timings = Timings(self, self._ticket)
-        return o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings, y_lengths
+        g = t.get
+        return (g("o"), g("o_mb"), g("spec"), g("phase"), g("attn"), g("y_mask"),
+                (g("z"), g("z_p"), g("m_p"), g("logs_p")), timings, y_lengths)
 
-    def _alloc_decoder_outputs(self, B, Td, dev):
+    def _alloc_decoder_outputs(self, B, Td, dev, want=None):
         f32 = dict(device=dev, dtype=torch.float32)
         spf = self.cfg.samples_per_frame
-        o = torch.empty(B, 1, spf * Td, **f32)
+        w = (lambda k: True) if want is None else (lambda k: k in want)
+        o = torch.empty(B, 1, spf * Td, **f32) if w("o") else None
         if self.cfg.decoder == DEC_SB:                         # models.py:300: (out, None, spec, phase)
             Fr = 64 * Td + 1
-            return o, None, torch.empty(B, 9, Fr, **f32), torch.empty(B, 9, Fr, **f32)
-        if self.cfg.decoder == DEC_MS:
-            o_mb = torch.empty(B, 4, spf * Td, **f32)         # zero-stuffed (models.py:463)
-        else:
-            o_mb = torch.empty(B, 4, (spf // 4) * Td, **f32)
+            return (o, None, torch.empty(B, 9, Fr, **f32) if w("spec") else None,
+                    torch.empty(B, 9, Fr, **f32) if w("phase") else None)
+        o_mb = None
+        if w("o_mb"):
+            if self.cfg.decoder == DEC_MS:
+                o_mb = torch.empty(B, 4, spf * Td, **f32)     # zero-stuffed (models.py:463)
+            else:
+                o_mb = torch.empty(B, 4, (spf // 4) * Td, **f32)
         Fr = 16 * Td + 1
-        spec = torch.empty(B, 4, 9, Fr, **f32)
-        phase = torch.empty(B, 4, 9, Fr, **f32)
+        spec = torch.empty(B, 4, 9, Fr, **f32) if w("spec") else None
+        phase = torch.empty(B, 4, 9, Fr, **f32) if w("phase") else None
         return o, o_mb, spec, phase
 
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
-              max_len=None):
-        """-> (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:737)"""
+              max_len=None, outputs=None):
+        """-> (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:737)
+
+        `outputs` (extension, default None = the reference's full tuple): names of the tensors to
+        materialise; the rest of the tuple is None.  A caller that only takes `[0]`
+        (tts_vits.py:134-137, synthesis_module.py:178-189) passes `outputs=("o",)` and gets the
+        waveform-only launch of the fused iSTFT+PQMF stage (no spec / phase / o_mb / attn stores)."""
         r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
-                      noise_scale_w=noise_scale_w)
+                      noise_scale_w=noise_scale_w, outputs=outputs)
         return r[:8]
 
     def infer_z_only(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
@@ -346,11 +400,11 @@ class SynthesizerTrn(nn.Module):
         return r[4], r[5], r[6], r[7]
 
     def infer_with_lengths(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
-                           max_len=None, noise_scale_w=1.):
+                           max_len=None, noise_scale_w=1., outputs=None):
         """`infer` plus the per-utterance frame counts y_lengths [B] (int64) — what a batched
         caller needs to trim the padded waveforms (valid samples = 256 * y_lengths)."""
         r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
-                      noise_scale_w=noise_scale_w)
+                      noise_scale_w=noise_scale_w, outputs=outputs)
         return r[:8], r[8]
 
     @torch.no_grad()
@@ -445,7 +499,7 @@ class SynthesizerTrn(nn.Module):
 
     def set_option(self, name, value):
         """Run-time options of the library (`mbv_set_option`): "splitk" (low-latency split-K for
-        small launches), "istft_exact".  Kept across weight refreshes; a
+        small launches), "istft_exact", "xpost_chunk_bytes".  Kept across weight refreshes; a
         handle re-created on another device starts from the defaults again."""
         h = self._ensure_handle()
         _capi.check(h, _capi.lib().mbv_set_option(h, name.encode(), int(value)), "mbv_set_option")

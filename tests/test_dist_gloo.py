@@ -33,10 +33,14 @@ class OracleNet:
     def _device(self):
         return torch.device("cpu")
 
-    def _run(self, x, xl, sid, noise_scale, length_scale, max_len, decode, frames_hook=None):
+    def _run(self, x, xl, sid, noise_scale, length_scale, max_len, decode, frames_hook=None,
+             stat_reduce=None, outputs=None, prior_rows=None):
         from oracle import ref_infer as R
         first = R.infer(self.sd, self.cfg, x, xl, sid, noise_scale=0.0, length_scale=length_scale)
-        tp = int(first["y_lengths"].max())
+        stat = torch.stack((first["y_lengths"].max(), torch.zeros((), dtype=torch.int64)))
+        if stat_reduce is not None:
+            stat_reduce(stat)
+        tp = int(stat[0])
         if frames_hook is not None:
             tp = frames_hook(tp)
         r = R.infer(self.sd, self.cfg, x, xl, sid, noise_scale=0.0, length_scale=length_scale, t_frames=tp)

@@ -1,0 +1,99 @@
+"""-m gpu: the sharded path with TWO ranks running the HIP kernels.
+
+A one-GPU box cannot host two RCCL ranks, so both child ranks use cuda:0 and the `gloo` backend;
+everything else is the product path: `dist.broadcast_state_dict`, `dist.sharded_infer` (its
+[T', error flag] all-reduce and the waveform all-gather run on CUDA tensors), `SynthesizerTrn._run`
+over `libmbistft_vits.so`.  The gathered result must equal, bitwise, a single-process `infer` of the
+whole batch — uneven shards (5 = 3 + 2), a multi-speaker model with `sid`, and the error paths.
+The real-RCCL N > 1 run is the driver's (`bench.py --gpus N` on an 8-GPU node)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_hip_sharded_infer_equals_full_batch(tmp_path):
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    port = _free_port()
+    world = 2
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_gpu_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=800)[0])
+    finally:
+        for p in procs:                         # exact PIDs we started; never by pattern
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-4000:])
+    res = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
+    assert all(r["native_loaded"] for r in res)
+    # every rank holds the same gathered result
+    for k in ("mini_b5", "uudb_b5", "mini_b4", "mini_b5_noise"):
+        assert torch.equal(res[0][k]["o"], res[1][k]["o"]), k
+    for r in res:
+        assert r["bad_token"] == "IndexError" and r["small_batch"] == "ValueError"
+        assert r["after_errors_equal"] and r["mini_b5_all_outputs_equal"]
+
+    # single-process full-batch reference on the same device, same kernels
+    for name, cfg_name, B, T in (("mini_b5", "ljs_mini_mb_istft_vits", 5, 23),
+                                 ("uudb_b5", "uudb_ms_istft_vits_ms", 5, 17),
+                                 ("mini_b4", "ljs_mini_mb_istft_vits", 4, 31)):
+        net, sd = make_net(cfg_name, seed=1300)
+        x, xl, sid = synth.synthetic_batch(net.cfg, B, T, seed=40 + B, ragged=True)
+        xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+        sidg = torch.from_numpy(sid).cuda() if sid is not None else None
+        (o, *_), ylen = net.infer_with_lengths(xg, xlg, sidg, noise_scale=0, length_scale=1)
+        assert torch.equal(res[0][name]["ylen"], ylen.cpu()), name
+        assert res[0][name]["o"].shape == o.shape, name
+        assert torch.equal(res[0][name]["o"], o.cpu()), name          # bitwise: global T' pad, same kernels
+        if name == "mini_b5":
+            torch.manual_seed(77)
+            torch.cuda.manual_seed(77)
+            o_n = net.infer(xg, xlg, sidg, noise_scale=0.6, length_scale=1)[0]
+            assert torch.equal(res[0]["mini_b5_noise"]["o"], o_n.cpu())
+            assert not torch.equal(o_n, o)
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launch_two_ranks_rehearsal(tmp_path):
+    """`python bench.py --gpus 2` as typed from a plain shell: the launcher starts the ranks as child
+    processes before any GPU call; on a box with fewer devices than ranks it says so in the JSON
+    (`rehearsal`), shares the device and uses gloo."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--t-text", "40", "--config", "ljs_mini_mb_istft_vits", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=800, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dist"]["world_size"] == 2 and len(j["dist"]["devices"]) == 2
+    assert j["config"]["global_batch"] == 8
+    if torch.cuda.device_count() < 2:
+        assert j["dist"]["rehearsal"] and j["dist"]["backend"] == "gloo"
+    assert j["value"] > 0

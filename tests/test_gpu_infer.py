@@ -272,32 +272,96 @@ def test_zero_length_utterance_in_batch():
     assert rms(o.cpu().numpy() - ref["o"].numpy()) < 1e-4
 
 
-def test_full_size_batch64_properties():
-    """BASELINE.json configs[1] at full size (ljs_mb, B=64, T_text=200): size-independent checks.
+@pytest.mark.parametrize("cfg_name,B", [("ljs_mb_istft_vits", 64), ("ljs_ms_istft_vits", 64),
+                                        ("uudb_ms_istft_vits_ms", 32)])
+def test_full_size_properties(cfg_name, B):
+    """BASELINE.json configs[1], configs[2] and the per-GPU share of configs[4] at full size
+    (ljs_mb / ljs_ms B=64, uudb B=32 with speaker ids; T_text=200): size-independent checks.
       * determinism: two runs are bitwise identical;
       * batch independence: a sub-batch run padded to the same T' reproduces its rows bitwise
         (no cross-utterance arithmetic anywhere on the path);
+      * `outputs=("o",)` (waveform-only launch) returns the same waveform bitwise;
       * spot parity: the oracle on two utterances at the same padded T' (the decoder is unmasked,
         so the pad length matters) agrees within the 1e-4 RMS bar."""
     from gpu_util import make_net
     from mb_istft_vits_amd import synth
-    net, sd = make_net("ljs_mb_istft_vits")
-    x, xl, _ = synth.synthetic_batch(net.cfg, 64, 200, seed=0)
+    net, sd = make_net(cfg_name)
+    x, xl, sid = synth.synthetic_batch(net.cfg, B, 200, seed=0)
     xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    sg = torch.from_numpy(sid).cuda() if sid is not None else None
     (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), _), ylen = net.infer_with_lengths(
-        xg, xlg, noise_scale=0, length_scale=1)
+        xg, xlg, sg, noise_scale=0, length_scale=1)
     Tp = z.shape[-1]
-    assert o.shape == (64, 1, 256 * Tp) and int(ylen.max()) == Tp
+    assert o.shape == (B, 1, 256 * Tp) and int(ylen.max()) == Tp
     assert torch.isfinite(o).all()
-    o2 = net.infer(xg, xlg, noise_scale=0, length_scale=1)[0]
+    o2 = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1)[0]
     assert torch.equal(o, o2)
-    r = net._run(xg[40:48], xlg[40:48], None, 0, 1, None, True, frames_hook=lambda t: Tp)
-    assert _same_rows(r[0], o[40:48]) and _same_rows(r[6][0], z[40:48])
+    only = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=("o",))
+    assert torch.equal(only[0], o) and all(t is None for t in only[1:6]) and all(t is None for t in only[6])
+    lo = B - 24
+    r = net._run(xg[lo:lo + 8], xlg[lo:lo + 8], sg[lo:lo + 8] if sg is not None else None, 0, 1, None, True,
+                 frames_hook=lambda t: Tp)
+    assert _same_rows(r[0], o[lo:lo + 8]) and _same_rows(r[6][0], z[lo:lo + 8])
     torch.set_num_threads(8)
-    ref = R.infer(sd, net.cfg, x[[3, 57]], xl[[3, 57]], t_frames=Tp)
-    got = o[[3, 57]].cpu().numpy()
-    assert np.array_equal(ylen[[3, 57]].cpu().numpy(), ref["y_lengths"].numpy())
+    pick = [3, B - 7]
+    ref = R.infer(sd, net.cfg, x[pick], xl[pick], sid[pick] if sid is not None else None, t_frames=Tp)
+    got = o[pick].cpu().numpy()
+    assert np.array_equal(ylen[pick].cpu().numpy(), ref["y_lengths"].numpy())
     assert rms(got - ref["o"].numpy()) < 1e-4
+
+
+def test_outputs_opt_in_subsets():
+    """`infer(outputs=...)`: any subset of the tuple is materialised alone, bitwise equal to the
+    full call; unknown names raise."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    for cfg_name in ("ljs_mini_mb_istft_vits", "ljs_mini_istft_vits", "uudb_ms_istft_vits_ms"):
+        net, sd = make_net(cfg_name)
+        x, xl, sid = synth.synthetic_batch(net.cfg, 3, 21, seed=8, ragged=True)
+        xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+        sg = torch.from_numpy(sid).cuda() if sid is not None else None
+        full = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1)
+        names = ("o", "o_mb", "spec", "phase", "attn", "y_mask")
+        for subset in (("o",), ("spec", "phase"), ("z", "attn"), ("o_mb", "y_mask", "m_p"), ()):
+            got = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=subset)
+            flat_full = dict(zip(names, full[:6]), **dict(zip(("z", "z_p", "m_p", "logs_p"), full[6])))
+            flat_got = dict(zip(names, got[:6]), **dict(zip(("z", "z_p", "m_p", "logs_p"), got[6])))
+            for k, v in flat_got.items():
+                if k in subset and flat_full[k] is not None:
+                    assert torch.equal(v, flat_full[k]), (cfg_name, subset, k)
+                else:
+                    assert v is None, (cfg_name, subset, k)
+    with pytest.raises(ValueError):
+        net.infer(xg, xlg, sg, noise_scale=0, outputs=("waveform",))
+
+
+def test_oversized_batch_is_split_not_refused():
+    """The fused iSTFT kernels address x_post with 32-bit byte offsets; a batch whose x_post reaches
+    2 GiB used to be refused and now runs conv_post + iSTFT in sub-batches with bitwise the unsplit
+    result.  (a) the split path forced at a small size through the `xpost_chunk_bytes` option, every
+    decoder family, all outputs; (b) a batch that really crosses 2 GiB on the single-band decoder
+    (x_post [B, 18, 64 T' + 1]), rows checked against a small batch padded alike."""
+    from gpu_util import make_net
+    rs = np.random.RandomState(11)
+    for cfg_name in ("ljs_mini_mb_istft_vits", "ljs_ms_istft_vits", "ljs_mini_istft_vits"):
+        net, sd = make_net(cfg_name)
+        z = torch.from_numpy(rs.standard_normal((7, 192, 19)).astype(np.float32)).cuda()
+        whole = net.dec(z)
+        utt_bytes = (18 * (64 * 19 + 1) if cfg_name == "ljs_mini_istft_vits" else 72 * (16 * 19 + 1)) * 4
+        net.set_option("xpost_chunk_bytes", 3 * utt_bytes + 100)      # sub-batches of 3, 3, 1
+        split = net.dec(z)
+        net.set_option("xpost_chunk_bytes", 0)
+        for a, b in zip(whole, split):
+            assert (a is None and b is None) or torch.equal(a, b), cfg_name
+    net, sd = make_net("ljs_mini_istft_vits")
+    B, Tp = 540, 870
+    assert B * 18 * (64 * Tp + 1) * 4 >= 2 ** 31
+    z = torch.randn(B, 192, Tp, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    o, _, spec, phase = net.dec(z)
+    assert o.shape == (B, 1, 256 * Tp) and torch.isfinite(o).all()
+    rows = [0, 1, 265, 266, B - 2, B - 1]
+    o_s, _, spec_s, _ = net.dec(z[rows].contiguous())
+    assert _same_rows(o_s, o[rows]) and _same_rows(spec_s, spec[rows])
 
 
 def test_voice_conversion_matches_reference_golden():

@@ -158,6 +158,30 @@ def test_pcm16_epilogue_bit_exact(net):
     assert np.array_equal(full[0], R.to_pcm16(wave[0, 0]))
 
 
+def test_pcm16_after_max_len_truncation(net):
+    """infer(max_len=k) returns rows of 256*k samples while y_lengths keeps the untruncated frame
+    counts (models.py:733-734): `to_pcm16(o, y_lengths)` must clamp each utterance to its row — the
+    peak of row b must not see row b+1, and the last row must not be read past its end."""
+    from mb_istft_vits_amd import synth
+    x, xl, _ = synth.synthetic_batch(net.cfg, 3, 20, seed=17, ragged=True)
+    (o, *_), ylen = net.infer_with_lengths(torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda(),
+                                           noise_scale=0, length_scale=1, max_len=12)
+    assert o.shape[-1] == 256 * 12 and int(ylen.max()) > 12
+    # make the rows' peaks very different, so a peak leaking across rows would change the scaling
+    scale = torch.tensor([1.0, 0.05, 3.0], device=o.device).view(3, 1, 1)
+    wave = (o * scale).contiguous()
+    pcm = net.to_pcm16(wave, ylen).cpu().numpy()
+    w = wave.cpu().numpy()
+    for b in range(3):
+        v = min(256 * int(ylen[b]), w.shape[-1])
+        assert np.array_equal(pcm[b, :v], R.to_pcm16(w[b, 0, :v], True)), b
+        assert not pcm[b, v:].any()
+    # negative lengths count as empty
+    neg = net.to_pcm16(wave, torch.tensor([-3, 2, 0], device=o.device)).cpu().numpy()
+    assert not neg[0].any() and not neg[2].any()
+    assert np.array_equal(neg[1, :512], R.to_pcm16(w[1, 0, :512], True))
+
+
 def test_c_abi_error_paths(net):
     """Misuse of the C ABI returns an error code + message (no crash, no exception across the ABI)."""
     import ctypes as C

@@ -153,3 +153,63 @@ def test_graft_entry_build_runs_without_gpu():
     """`__graft_entry__.build()` is the driver's does-it-build check on the CPU container."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_timings_dict_behaves_like_the_reference_plain_dict():
+    """`timings` (models.py:698-737) is a plain dict in the reference; ours fills itself lazily from
+    HIP events, and EVERY way of reading it must see the resolved values."""
+    import json
+    import pickle
+    from mb_istft_vits_amd.models import Timings, _STAGES
+
+    class Owner:
+        calls = 0
+
+        def _stage_times(self, ticket):
+            Owner.calls += 1
+            return [0.001 * (i + 1) for i in range(5)]
+
+    want = {k: 0.001 * (i + 1) for i, k in enumerate(_STAGES)}
+    assert json.loads(json.dumps(Timings(Owner(), 1))) == want
+    assert Timings(Owner(), 1).get("flow") == want["flow"]
+    assert Timings(Owner(), 1).get("nope", 7) == 7
+    assert Timings(Owner(), 1).copy() == want
+    assert Timings(Owner(), 1) == want and not (Timings(Owner(), 1) != want)
+    assert Timings(Owner(), 1) != {}
+    assert pickle.loads(pickle.dumps(Timings(Owner(), 1))) == want
+    assert dict(Timings(Owner(), 1)) == want and {**Timings(Owner(), 1)} == want
+    assert list(Timings(Owner(), 1)) == list(_STAGES) and len(Timings(Owner(), 1)) == 5
+    assert sorted(Timings(Owner(), 1).values()) == sorted(want.values())
+    t = Timings(Owner(), 1)
+    n = Owner.calls
+    assert t["flow"] == want["flow"] and t["text_encoder"] == want["text_encoder"] and "flow" in t
+    assert Owner.calls == n + 1                      # resolved once
+
+
+def test_bench_self_launch_builds_a_child_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: ranks are started as CHILD processes
+    (torch.distributed.run), never by replacing this process; with fewer devices than ranks the
+    launcher switches to the marked rehearsal mode."""
+    import importlib
+    import sys
+    bench = importlib.import_module("bench")
+    import torch
+    calls = {}
+
+    def fake_call(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_launch(bench.parse_args(["--gpus", "4", "--steps", "2"])) == 0
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and "4" in cmd
+    assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert calls["env"]["MBV_BENCH_SHARE_DEVICES"] == "1" and calls["env"]["MBV_BENCH_BACKEND"] == "gloo"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    bench.self_launch(bench.parse_args(["--gpus", "4"]))
+    assert "MBV_BENCH_SHARE_DEVICES" not in calls["env"]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    assert bench.self_launch(bench.parse_args(["--gpus", "2"])) == 1
