@@ -68,11 +68,11 @@ struct mbv_model {
   struct Dds { PVec sw[3], sb[3], g1[3], b1[3], g2[3], b2[3]; PConv c1[3]; };
   struct SdpFlow { PVec pre_w, pre_b; Dds dds; PConv proj; };
   struct Sdp { PConv pre, proj; Dds dds; SdpFlow flow[3]; PVec m, logs; float edge_const = 0.f; } sdp;
-  struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers]; PVec cw, cb; };
+  struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers], in16[kFlowLayers], rsp[kFlowLayers]; PVec cw, cb; };
   Flow flow[kNFlows];
   PConv conv_pre, conv_post;
   static constexpr int kEncQLayers = 16;     // models.py:646
-  struct EncQ { PConv pre, proj, in[kEncQLayers], rs[kEncQLayers]; PVec cw, cb; int cin_pad = 0; } encq;
+  struct EncQ { PConv pre, proj, in[kEncQLayers], rs[kEncQLayers], in16[kEncQLayers], rsp[kEncQLayers]; PVec cw, cb; int cin_pad = 0; } encq;
   struct Up { size_t w = 0, bias = 0; int Cin = 0, Cout = 0, Mpad = 0; } ups[2];
   PConv upc[2];              // stride-4 ups as 5-tap convs over the output phases (EPI_CONVT)
   struct RB { PConv c1[3], c2[3]; PVec cw, cb; } rb[6];
@@ -82,6 +82,7 @@ struct mbv_model {
   // scratch
   float* conv_ws = nullptr; size_t conv_ws_floats = 0;   // split-K partials of small conv launches
   unsigned* conv_cnt = nullptr; int conv_ncnt = 0;        // one ticket counter per tile (zero between launches)
+  int wn_fused = 1;           // MBV_WN_FUSED=0: the two-launch WN layer (gate conv, then res/skip conv)
   int splitk = 0;             // option "splitk": split-K for small conv launches (default: MBV_CONV_SPLITK or 0)
   char* scrA = nullptr; size_t scrA_bytes = 0;
   char* scrB = nullptr; size_t scrB_bytes = 0;
@@ -416,6 +417,32 @@ PConv pack_gated(Packer& P, const std::string& prefix, int H, int K) {
   return P.conv(w, 2 * H, H, K, rows, {}, &P.t(prefix + ".bias").data, &brows);
 }
 
+// The same in_layer for the fused WN kernel (wn_fused.hip): 32-row tiles of
+// [tanh 16t..16t+7 | sigmoid 16t..16t+7 | tanh 16t+8..16t+15 | sigmoid 16t+8..16t+15], which puts the
+// tanh and the sigmoid row of a channel into the same lane of the 32x32 accumulator.  The bias
+// stays in reference order.
+PConv pack_gated16(Packer& P, const std::string& prefix, int H, int K) {
+  const std::vector<float> w = P.dense(prefix);
+  std::vector<int> rows(2 * H), brows(2 * H);
+  for (int r = 0; r < 2 * H; ++r) {
+    const int tile = r / 32, rho = r % 32;
+    const int ch = tile * 16 + (rho & 7) + 8 * (rho >> 4);
+    rows[r] = (rho & 8) ? H + ch : ch;
+    brows[r] = r;
+  }
+  return P.conv(w, 2 * H, H, K, rows, {}, &P.t(prefix + ".bias").data, &brows);
+}
+// res_skip 1x1 with the input channels in the order the gated tile leaves the accumulators
+PConv pack_rs_permuted(Packer& P, const std::string& prefix) {
+  const std::vector<float> w = P.dense(prefix);
+  const auto& sh = P.t(prefix + ".weight_v").shape;
+  const int Cout = (int)sh[0], Cin = (int)sh[1];
+  std::vector<int> rows(Cout), cmap(Cin);
+  for (int i = 0; i < Cout; ++i) rows[i] = i;
+  for (int ci = 0; ci < Cin; ++ci) cmap[ci] = 8 * (ci / 8) + 4 * (ci & 1) + ((ci & 7) >> 1);
+  return P.conv(w, Cout, Cin, 1, rows, cmap, &P.t(prefix + ".bias").data, nullptr);
+}
+
 // modified Bessel I0 (power series; converges fast for x <= 9)
 double bessel_i0(double x) {
   double sum = 1.0, term = 1.0;
@@ -574,8 +601,10 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       char q[64];
       snprintf(q, sizeof q, "enc.in_layers.%d", l);
       F.in[l] = pack_gated(P, s + q, H, kFlowK);
+      if (wn_fused_supported(H, kFlowK)) F.in16[l] = pack_gated16(P, s + q, H, kFlowK);
       snprintf(q, sizeof q, "enc.res_skip_layers.%d", l);
       F.rs[l] = P.conv_plain(s + q);
+      if (wn_fused_supported(H, kFlowK)) F.rsp[l] = pack_rs_permuted(P, s + q);
     }
     if (gin) {
       F.cw = P.vec_data(P.dense(s + "enc.cond_layer"));
@@ -605,8 +634,10 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       char q[64];
       snprintf(q, sizeof q, "enc_q.enc.in_layers.%d", l);
       Q.in[l] = pack_gated(P, q, H, 5);
+      if (wn_fused_supported(H, 5)) Q.in16[l] = pack_gated16(P, q, H, 5);
       snprintf(q, sizeof q, "enc_q.enc.res_skip_layers.%d", l);
       Q.rs[l] = P.conv_plain(q);
+      if (wn_fused_supported(H, 5)) Q.rsp[l] = pack_rs_permuted(P, q);
     }
     if (gin) {
       Q.cw = P.vec_data(P.dense("enc_q.enc.cond_layer"));
@@ -920,15 +951,39 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
 }
 
 
-// WN stack (modules.py:148-176): h (in place) -> skip; `nl` layers, gate conditioning from gvec
-int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, int nl, const PVec& cw, const PVec& cb,
-           const float* gvec, float* hbuf, float* acts, float* skip, float* gc, const int* lens, int B,
-           int T, hipStream_t s) {
+// WN stack (modules.py:148-176): h -> skip; `nl` layers, gate conditioning from gvec.
+// Fused path (default): one launch per layer over the units that hold valid frames, h ping-pongs
+// between hbuf and acts (the old path's gated-activation buffer); afterwards only `skip` is meaningful,
+// and only where the frame mask is 1 (every reader masks on load).
+// Two-launch path (MBV_WN_FUSED=0, or small launches in the low-latency split-K mode, where one
+// workgroup per 32-frame unit would leave most of the chip idle): gate conv, then res/skip conv.
+int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16_l, const PConv* rsp_l, int nl,
+           const PVec& cw, const PVec& cb, const float* gvec, float* hbuf, float* acts, float* skip, float* gc,
+           int* ustart, const int* lens, int B, int T, hipStream_t s) {
   const mbv_config& c = m->cfg;
   const int H = c.hidden_channels, gin = c.gin_channels;
   const int64_t bsH = (int64_t)H * T;
   const bool cond = gvec && gin && cw.present;
   if (cond) launch_cond_gemv(gvec, nullptr, nullptr, m->W(cw.off), m->W(cb.off), gc, B, gin, 2 * H * nl, s);
+  const bool small = (long)B * ((T + 31) / 32) < 192;
+  if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && !(m->splitk && small)) {
+    launch_wn_units(lens, B, T, ustart, s);
+    float* hin = hbuf;
+    float* hout = acts;
+    for (int l = 0; l < nl; ++l) {
+      WnLayerArgs a{};
+      a.h_in = hin; a.h_out = hout; a.skip = skip; a.lens = lens; a.ustart = ustart;
+      a.wg = m->W(in16_l[l].w); a.bg = m->W(in16_l[l].bias);
+      if (cond) { a.gcond = gc + (size_t)l * 2 * H; a.gcond_bstride = 2 * H * nl; }
+      a.wr = m->W(rsp_l[l].w); a.br = m->W(rsp_l[l].bias);
+      a.B = B; a.H = H; a.T = T;
+      a.Mg_pad = in16_l[l].Mpad; a.Mr = rsp_l[l].M; a.Mr_pad = rsp_l[l].Mpad;
+      a.last = rsp_l[l].M == H; a.skip_accum = l > 0;
+      launch_wn_layer(a, s);
+      float* tmp = hin; hin = hout; hout = tmp;
+    }
+    return 0;
+  }
   for (int l = 0; l < nl; ++l) {
     {
       ConvArgs a = conv_args(m, in_l[l], hbuf, bsH, T, acts, bsH, T, B);
@@ -951,7 +1006,7 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, int nl, const PVe
 // precedes (reverse) / follows (forward) it is folded into the packing, see do_finalize.
 //   reverse: x1 = (x1 - m) * mask          forward: x1 = m + x1 * mask = (x1 + m) * mask
 int run_coupling(mbv_model* m, int f, bool reverse, float* z, const float* gvec, float* hbuf, float* acts,
-                 float* skip, float* gc, const int* lens, int B, int T, hipStream_t s) {
+                 float* skip, float* gc, int* ustart, const int* lens, int B, int T, hipStream_t s) {
   const mbv_config& c = m->cfg;
   const int H = c.hidden_channels, I = c.inter_channels, half = I / 2;
   const int64_t bsI = (int64_t)I * T, bsH = (int64_t)H * T;
@@ -964,7 +1019,7 @@ int run_coupling(mbv_model* m, int f, bool reverse, float* z, const float* gvec,
     a.out_lens = lens;
     launch_conv1d(a, s);
   }
-  run_wn(m, F.in, F.rs, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, lens, B, T, s);
+  run_wn(m, F.in, F.rs, F.in16, F.rsp, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, ustart, lens, B, T, s);
   {
     ConvArgs a = conv_args(m, F.post, skip, bsH, T, x1, bsI, T, B);
     a.in_lens = lens; a.epi = EPI_COUPLE; a.out_lens = lens;
@@ -1034,6 +1089,7 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   m->cfg = *cfg;
   { const char* e = getenv("MBV_ISTFT_EXACT"); m->exact_math = (e && e[0] == '1') ? 1 : 0; }
   { const char* e = getenv("MBV_CONV_SPLITK"); m->splitk = (e && atoi(e) != 0) ? 1 : 0; }
+  { const char* e = getenv("MBV_WN_FUSED"); m->wn_fused = e ? (atoi(e) != 0) : 1; }
   build_expected(m);
   for (auto& e : m->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
@@ -1062,8 +1118,9 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!name) return m->fail("mbv_set_option: name is NULL");
   if (!strcmp(name, "splitk")) { m->splitk = value != 0; return 0; }
   if (!strcmp(name, "istft_exact")) { m->exact_math = value != 0; return 0; }
+  if (!strcmp(name, "wn_fused")) { m->wn_fused = value != 0; return 0; }
   if (!strcmp(name, "xpost_chunk_bytes")) { m->xpost_chunk_bytes = value > 0 ? value : 0; return 0; }
-  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, xpost_chunk_bytes)", name);
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes)", name);
 }
 
 void mbv_destroy(mbv_model* m) {
@@ -1295,7 +1352,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   const int Td = (max_len > 0 && max_len < Tp) ? max_len : Tp;
   const size_t BTp = (size_t)B * Tp;
   const bool run_dec = outs && (outs->o || outs->o_mb || outs->spec || outs->phase);
-  size_t need = (BTp * (4 * I + 3 * H) + (size_t)B * 2 * H * kFlowLayers) * 4 + 64 * 256 +
+  size_t need = (BTp * (4 * I + 3 * H) + (size_t)B * (2 * H * kFlowLayers + 2)) * 4 + 64 * 256 +
                 decoder_scratch_bytes(c, B, Td);
   if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
   Bump sc{m->scrB, m->scrB_bytes};
@@ -1306,6 +1363,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   float* acts = sc.take<float>(BTp * H);
   float* skip = sc.take<float>(BTp * H);
   float* gc = sc.take<float>((size_t)B * 2 * H * kFlowLayers);
+  int* ustart = sc.take<int>((size_t)B + 1);
   (void)gin;
 
   HIPCHK(m, hipEventRecord(m->ev[3], s));
@@ -1318,7 +1376,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
 
   // ---- reverse flows, in place on z (models.py:207-214, modules.py:334-353)
   for (int f = kNFlows - 1; f >= 0; --f)
-    run_coupling(m, f, true, z, m->has_g ? m->gvec : nullptr, hbuf, acts, skip, gc, m->ylen32, B, Tp, s);
+    run_coupling(m, f, true, z, m->has_g ? m->gvec : nullptr, hbuf, acts, skip, gc, ustart, m->ylen32, B, Tp, s);
   HIPCHK(m, hipEventRecord(m->ev[5], s));
   if (run_dec) {
     if (run_decoder(m, z, Tp, m->ylen32, m->has_g ? m->gvec : nullptr, B, Td, outs, s, sc)) return 1;
@@ -1416,7 +1474,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
   const int H = c.hidden_channels, I = c.inter_channels, gin = c.gin_channels, SC = c.spec_channels;
   const auto& Q = m->encq;
   const size_t BT = (size_t)B * T;
-  size_t need = (BT * ((size_t)Q.cin_pad + 3 * H + 4 * I) + (size_t)B * (2 * gin + 2 * H * mbv_model::kEncQLayers + 16)) * 4 +
+  size_t need = (BT * ((size_t)Q.cin_pad + 3 * H + 4 * I) + (size_t)B * (2 * gin + 2 * H * mbv_model::kEncQLayers + 18)) * 4 +
                 64 * 256 + decoder_scratch_bytes(c, B, T);
   if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
   Bump sc{m->scrB, m->scrB_bytes};
@@ -1433,6 +1491,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
   float* gc = sc.take<float>((size_t)B * 2 * H * mbv_model::kEncQLayers);
   int* lens = sc.take<int>(B);
   int* bad = sc.take<int>(B);
+  int* ustart = sc.take<int>((size_t)B + 1);
 
   launch_lens_to_i32(y_lengths, lens, B, T, bad, s);
   launch_gather_rows(m->W(m->emb_g.off), sid_src, g_src, B, gin, c.n_speakers, bad, s);
@@ -1448,7 +1507,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
     a.out_lens = lens;
     launch_conv1d(a, s);
   }
-  run_wn(m, Q.in, Q.rs, mbv_model::kEncQLayers, Q.cw, Q.cb, g_src, hbuf, acts, skip, gc, lens, B, T, s);
+  run_wn(m, Q.in, Q.rs, Q.in16, Q.rsp, mbv_model::kEncQLayers, Q.cw, Q.cb, g_src, hbuf, acts, skip, gc, ustart, lens, B, T, s);
   {
     ConvArgs a = conv_args(m, Q.proj, skip, bsH, T, stats, (int64_t)2 * I * T, T, B);
     a.in_lens = lens; a.out_lens = lens;
@@ -1458,10 +1517,10 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
   // forward flow with the source speaker (models.py:795), then reverse with the target (:796)
   HIPCHK(m, hipMemcpyAsync(zhat, zbuf, BT * I * 4, hipMemcpyDeviceToDevice, s));
   for (int f = 0; f < kNFlows; ++f)
-    run_coupling(m, f, false, zhat, g_src, hbuf, acts, skip, gc, lens, B, T, s);
+    run_coupling(m, f, false, zhat, g_src, hbuf, acts, skip, gc, ustart, lens, B, T, s);
   if (outs->z_p) HIPCHK(m, hipMemcpyAsync(outs->z_p, zhat, BT * I * 4, hipMemcpyDeviceToDevice, s));
   for (int f = kNFlows - 1; f >= 0; --f)
-    run_coupling(m, f, true, zhat, g_tgt, hbuf, acts, skip, gc, lens, B, T, s);
+    run_coupling(m, f, true, zhat, g_tgt, hbuf, acts, skip, gc, ustart, lens, B, T, s);
   if (outs->y_mask) launch_sequence_mask(lens, outs->y_mask, B, T, s);
   if (run_decoder(m, zhat, T, lens, g_tgt, B, T, outs, s, sc)) return 1;
   HIPCHK(m, hipGetLastError());

@@ -249,8 +249,15 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
           polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
           if (own) {
             const int so = ((b * 4 + band) * 9 * F + f) * 4;
-            if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
-            if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 0);
+            // write-once streams larger than the Infinity Cache: non-temporal, so that x_post (just
+            // written by subband_conv_post) is not pushed out of the cache ahead of its reads
+            if (a.nt_stores) {
+              if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 2);
+              if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 2);
+            } else {
+              if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 0);
+              if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 0);
+            }
           }
         }
       }
@@ -295,13 +302,22 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
       }
       if (a.o_mb && u >= 8 && u < TM + 8) {          // owned samples m0 .. m0+TM-1
         if (!a.multistream) {
+          if (a.nt_stores) {
 #pragma unroll
-          for (int band = 0; band < 4; ++band) a.o_mb[((int64_t)b * 4 + band) * M + m] = y[band];
+            for (int band = 0; band < 4; ++band)
+              __builtin_nontemporal_store(y[band], &a.o_mb[((int64_t)b * 4 + band) * M + m]);
+          } else {
+#pragma unroll
+            for (int band = 0; band < 4; ++band) a.o_mb[((int64_t)b * 4 + band) * M + m] = y[band];
+          }
         } else {                                       // zero-stuffed x4, gain 4 (models.py:463)
+          typedef float f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-          for (int band = 0; band < 4; ++band)
-            *reinterpret_cast<float4*>(a.o_mb + ((int64_t)b * 4 + band) * 4 * M + 4 * (int64_t)m) =
-                make_float4(4.f * y[band], 0.f, 0.f, 0.f);
+          for (int band = 0; band < 4; ++band) {
+            f4v v = {4.f * y[band], 0.f, 0.f, 0.f};
+            f4v* dst = reinterpret_cast<f4v*>(a.o_mb + ((int64_t)b * 4 + band) * 4 * M + 4 * (int64_t)m);
+            if (a.nt_stores) __builtin_nontemporal_store(v, dst); else *dst = v;
+          }
         }
       }
     }
@@ -394,7 +410,10 @@ static void launch_istft_pqmf_t(const IstftArgs& a, hipStream_t s) {
 #undef MBV_ISTFT_LAUNCH
 }
 
-void launch_istft_pqmf(const IstftArgs& a, hipStream_t s) {
+void launch_istft_pqmf(const IstftArgs& a_in, hipStream_t s) {
+  IstftArgs a = a_in;
+  static const int nt = [] { const char* e = getenv("MBV_ISTFT_NT"); return e ? atoi(e) : 1; }();
+  a.nt_stores = nt;
   // 480 sub-band samples x 512 threads (4 workgroups / CU) by default; MBV_ISTFT_TILE=224 selects
   // the 224 x 256-thread shape (8 workgroups / CU) for A/B runs
   static const int tile = [] { const char* e = getenv("MBV_ISTFT_TILE"); return e ? atoi(e) : 480; }();

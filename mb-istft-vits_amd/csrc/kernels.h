@@ -74,6 +74,35 @@ struct ConvArgs {
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
 
+// ---------------------------------------------------------------- fused WN layer (wn_fused.hip)
+// One layer of modules.WN (k = 5, dilation 1) in one launch: gate conv + tanh*sigmoid + 1x1 res/skip +
+// residual / skip update, over the 32-frame units that hold valid frames.
+//   wg  gate conv packed like every conv (Wp[tap][H/8][ci & 1][Mg_pad][(ci % 8) / 2]) with the ROWS in
+//       tiles of 32 = [tanh ch 16t..16t+7 | sigmoid 16t..16t+7 | tanh 16t+8..16t+15 | sigmoid 16t+8..16t+15]
+//   wr  res/skip 1x1 packed with natural rows and the input channels permuted: packed channel ci
+//       <- source channel 8 (ci / 8) + 4 (ci & 1) + ((ci & 7) >> 1)   (the order the gated tile leaves
+//       the accumulators in)
+//   bg / gcond in reference row order ([tanh rows | sigmoid rows]); br natural.
+struct WnLayerArgs {
+  const float* h_in;       // [B, H, T]  (read with the frame mask applied)
+  float* h_out;            // [B, H, T]  != h_in; unused when last
+  float* skip;             // [B, H, T]
+  const int* lens;         // [B]
+  const int* ustart;       // [B + 1]: launch_wn_units
+  const float* wg; const float* bg;
+  const float* gcond;      // [B, gcond_bstride] already offset to this layer, or nullptr
+  int gcond_bstride;
+  const float* wr; const float* br;
+  int B, H, T;
+  int Mg_pad;              // padded rows of wg
+  int Mr, Mr_pad;          // rows of the res/skip conv (2H, or H for the last layer)
+  int last;                // Mr == H: every row goes to skip
+  int skip_accum;          // skip += (layers > 0) instead of skip =
+};
+bool wn_fused_supported(int H, int K);
+void launch_wn_units(const int* lens, int B, int T, int* ustart, hipStream_t s);
+void launch_wn_layer(const WnLayerArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- ConvTranspose1d k=16, stride 4 / 8 (MFMA)
 // Packed: Wt[r][j][Cin][Mpad] with Wt[r][j][ci][co] = W[ci][co][(r + pad) % stride + stride * j],
 // r < stride, j < 16 / stride, pad = (16 - stride) / 2
@@ -152,6 +181,7 @@ struct IstftArgs {
   int exact_math;        // 1: libm expf/sinf/sincosf instead of the hardware transcendentals
   int prescaled;         // 1: x_post rows already carry log2(e) (magnitude) / 1/(2 pi) (phase)
   int polar_in;          // 1: x_post unused; spec / phase [B,4,9,F] are the INPUT (istft_finalize)
+  int nt_stores;         // set by the launcher (MBV_ISTFT_NT, default 1): non-temporal stores for spec / phase / o_mb
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
 

@@ -1,0 +1,324 @@
+// One WN layer (modules.py:148-176 + commons.py:100-107) in ONE launch:
+//
+//   x_in = conv_k5(h) + b (+ g_l)            in_layers[l]        192 -> 384, weight-normed
+//   acts = tanh(x_in[:H]) * sigmoid(x_in[H:])                    fused_add_tanh_sigmoid_multiply
+//   rs   = W_rs . acts + b_rs                res_skip_layers[l]  192 -> 384 (last layer: -> 192)
+//   h    = (h + rs[:H]) * mask ; skip += rs[H:]                  (last layer: skip += rs)
+//
+// Work unit = 32 consecutive frames of one utterance; only units that hold valid frames
+// (t0 < len[b]) exist — everything the flows / the posterior encoder compute is masked, and every
+// reader of h / skip masks on load, so padded frames are neither computed nor written.  The unit
+// table (prefix sums of ceil(len / 32)) is built once per WN stack by wn_units_kernel.
+//
+// A 256-thread workgroup owns one unit at a time; its 4 waves (one per SIMD) split the ROWS:
+//   gate GEMM   [2H x 5H] . [5H x 32]   row tile t (32 packed rows = 16 tanh + 16 sigmoid rows of
+//                                       channels 16t..16t+15) -> wave t % 4
+//   gating      in registers: the packing puts the tanh and the sigmoid row of a channel into the
+//               same lane (registers r and r + 4 of the 32x32 accumulator)
+//   rs GEMM     [Mr x H] . [H x 32]     the gated tile goes through LDS once, written as the
+//               k-interleaved B image the MFMA loop reads (the k order of that product is
+//               whatever the accumulator layout yields; W_rs is packed to match on the host)
+// Weights are NOT staged in LDS: every wave needs different rows, so a lane's A operand (four
+// K-steps = one 16-byte load, 512 contiguous bytes per half wave in the packed layout) comes
+// straight from L2 through a register ring filled five (gate) / four (rs) steps ahead.  The only
+// LDS traffic is the input window (all H channels x 36 frames, staged once per unit) and the gated
+// tile; two barriers per unit, none inside the MFMA loops.  Two workgroups per CU cover each
+// other's prologue / gating / epilogue.
+#include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace mbv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kK = 5;            // WN kernel size of the flows and of enc_q (models.py:646-647)
+constexpr int kUnit = 32;        // frames per unit
+constexpr int kXL = kUnit + kK - 1;
+__device__ __forceinline__ float sigmoid_(float v) { return 1.f / (1.f + expf(-v)); }
+}  // namespace
+
+// ustart[b] = sum_{b' < b} ceil(len[b'] / 32), ustart[B] = number of units
+__global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x;
+  const int per = (B + 255) / 256;
+  int s = 0;
+  for (int i = 0; i < per; ++i) {
+    const int b = tid * per + i;
+    if (b < B) { int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l); s += (l + kUnit - 1) / kUnit; }
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = 0; i < per; ++i) {
+    const int b = tid * per + i;
+    if (b < B) {
+      ustart[b] = run;
+      int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l);
+      run += (l + kUnit - 1) / kUnit;
+      if (b == B - 1) ustart[B] = run;
+    }
+  }
+}
+
+void launch_wn_units(const int* lens, int B, int T, int* ustart, hipStream_t s) {
+  hipLaunchKernelGGL(wn_units_kernel, dim3(1), dim3(256), 0, s, lens, B, T, ustart);
+}
+
+// raw buffer access: one 32-bit lane offset per tensor, every row / step stride rides in a scalar
+// register (64-bit per-access pointers made the unrolled loads below spill); out-of-range lanes read 0
+// and their stores are dropped, which doubles as the frame mask.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRsrcFlags = 0x00020000;
+constexpr unsigned kOob = 0x7fffffffu;          // lane offset of a masked lane (beyond every range)
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
+}
+
+// NRT = row tiles per wave (ceil(2H / 32 / 4)): 3 for H = 192 / 160, 2 for H <= 128
+template <int NRT>
+__global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int H = a.H, T = a.T;
+  const int G = H / 8;                         // 8-channel groups (4 K-steps each)
+  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [G][2][kXL]
+  f32x4* const As = Xs + G * 2 * kXL;                        // [G][2][32]
+  const int ntg = 2 * H / 32;                  // gate row tiles
+  const int ntr = a.Mr / 32;                   // res/skip row tiles
+  int nact_g = (ntg - wave + 3) / 4;  nact_g = nact_g > NRT ? NRT : nact_g;   // wave-uniform
+  int nact_r = (ntr - wave + 3) / 4;  nact_r = nact_r > NRT ? NRT : nact_r;
+  const int U = a.ustart[a.B];
+
+  // packed weights W[step][h][Mpad][4 floats], step = tap * G + g: lane offset + scalar step offset
+  const __amdgpu_buffer_rsrc_t wg_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wg), 0, kK * H * a.Mg_pad * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t wr_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wr), 0, H * a.Mr_pad * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t bg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bg), 0, 2 * H * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t br_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.br), 0, a.Mr * 4, kRsrcFlags);
+  const unsigned wg_voff = (unsigned)((hl * a.Mg_pad + wave * 32 + l31) * 16);
+  const unsigned wr_voff = (unsigned)((hl * a.Mr_pad + wave * 32 + l31) * 16);
+  const unsigned wg_step = (unsigned)(2 * a.Mg_pad * 16), wr_step = (unsigned)(2 * a.Mr_pad * 16);
+  const unsigned rowT = (unsigned)T * 4u;      // bytes between channel rows of h / skip
+  const unsigned utt_bytes = (unsigned)H * rowT;
+
+  for (int u = blockIdx.x; u < U; u += gridDim.x) {
+    int b;
+    {
+      int lo = 0, hi = a.B - 1;                // largest b with ustart[b] <= u
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.ustart[mid] <= u) lo = mid; else hi = mid - 1;
+      }
+      b = lo;
+    }
+    const int t0 = (u - a.ustart[b]) * kUnit;
+    int len = a.lens[b];
+    len = len > T ? T : len;
+    const int t = t0 + l31;                    // this lane's frame
+    const bool tv = t < len;
+    // per-utterance views of h_in / h_out / skip
+    const __amdgpu_buffer_rsrc_t hin_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.h_in) + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t hout_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.h_out + (int64_t)b * H * T, 0, a.last ? 0 : utt_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t skip_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.skip + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gc_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.gcond) + (a.gcond ? (int64_t)b * a.gcond_bstride : 0), 0, a.gcond ? 2 * H * 4 : 0, kRsrcFlags);
+
+    // ---- A ring of the gate GEMM: the five taps of group 0 -------------------------------
+    f32x4 ra[kK][NRT];
+#pragma unroll
+    for (int tap = 0; tap < kK; ++tap)
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+        if (j < nact_g) ra[tap][j] = bload4(wg_rs, wg_voff, (unsigned)(tap * G) * wg_step + j * 2048u);
+
+    __syncthreads();                           // the previous unit's readers of Xs / As are done
+    // ---- input window: all H channels x 36 frames, masked, k-interleaved ------------------
+    {
+      const int items = G * 2 * kXL;
+      for (int e = tid; e < items; e += 256) {
+        const int P = e / kXL, c = e - P * kXL;
+        const int ti = t0 - (kK - 1) / 2 + c;
+        const unsigned vo = (ti >= 0 && ti < len) ? (unsigned)(((P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
+        f32x4 v;
+        v[0] = bload1(hin_rs, vo, 0); v[1] = bload1(hin_rs, vo, 2 * rowT);
+        v[2] = bload1(hin_rs, vo, 4 * rowT); v[3] = bload1(hin_rs, vo, 6 * rowT);
+        Xs[e] = v;
+      }
+    }
+    // ---- gate accumulators start from bias (+ speaker conditioning) -------------------------
+    f32x16 acc[NRT];
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) {
+      // packed row (r, hl) of tile `wave + 4 j`: registers 0-3 / 8-11 tanh, 4-7 / 12-15 sigmoid of
+      // channel 16 tile + (r & 3) + 8 (r >> 3) + 4 hl
+      const unsigned vo = j < nact_g ? (unsigned)(4 * hl) * 4u : kOob;
+      const unsigned so = (unsigned)((wave + 4 * j) * 16) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned sr = so + (unsigned)(((r & 3) + 8 * (r >> 3)) * 4) + ((r & 4) ? (unsigned)H * 4u : 0u);
+        acc[j][r] = bload1(bg_rs, vo, sr) + bload1(gc_rs, vo, sr);      // gc_rs is empty without conditioning: reads 0
+      }
+    }
+    __syncthreads();
+
+    // ---- gate GEMM ---------------------------------------------------------------------------
+    {
+      const f32x4* xl = Xs + hl * kXL + l31;
+      for (int g = 0; g < G; ++g) {
+        const int gn = g + 1 < G ? g + 1 : g;  // last group re-loads itself (unused)
+#pragma unroll
+        for (int tap = 0; tap < kK; ++tap) {
+          const f32x4 bv = xl[g * 2 * kXL + tap];
+          f32x4 av[NRT];
+#pragma unroll
+          for (int j = 0; j < NRT; ++j) av[j] = ra[tap][j];
+#pragma unroll
+          for (int j = 0; j < NRT; ++j)
+            if (j < nact_g) ra[tap][j] = bload4(wg_rs, wg_voff, (unsigned)(tap * G + gn) * wg_step + j * 2048u);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = 0; j < NRT; ++j)
+              if (j < nact_g) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s4], bv[s4], acc[j], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- A ring of the rs GEMM (issued before the gating arithmetic, which hides its latency) ----
+    constexpr int DR = 4;
+    f32x4 rb[DR][NRT];
+#pragma unroll
+    for (int d = 0; d < DR; ++d)
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+        if (j < nact_r) rb[d][j] = bload4(wr_rs, wr_voff, (unsigned)d * wr_step + j * 2048u);
+
+    // ---- gating, gated tile -> LDS as the B image of the rs GEMM ------------------------------
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) {
+      if (j < nact_g) {
+        const int tile = wave + 4 * j;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] = tanhf(acc[j][8 * q + s]) * sigmoid_(acc[j][8 * q + s + 4]);
+          As[((2 * tile + q) * 2 + hl) * 32 + l31] = v;        // channels 16 tile + 8 q + 4 hl + s
+        }
+      }
+    }
+    // ---- rs accumulators start from bias + what the layer updates in place -------------------
+    // rows of tile `wave + 4 j`: (r & 3) + 8 (r >> 2) + 4 hl; frames past the utterance read 0
+    f32x16 acr[NRT];
+    const unsigned io_voff = tv ? (unsigned)(4 * hl * T + t) * 4u : kOob;
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) {
+      const int row0 = (wave + 4 * j) * 32;
+      const bool is_res = !a.last && row0 < H;                // wave-uniform (H % 32 == 0)
+      const unsigned srow0 = (unsigned)(a.last ? row0 : row0 - H);
+      const unsigned bvo = j < nact_r ? (unsigned)(4 * hl) * 4u : kOob;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+        float v = bload1(br_rs, bvo, (unsigned)(row0 + k) * 4u);
+        if (j < nact_r) {
+          if (is_res) v += bload1(hin_rs, io_voff, (unsigned)(row0 + k) * rowT);
+          else if (a.skip_accum) v += bload1(skip_rs, io_voff, (srow0 + k) * rowT);
+        }
+        acr[j][r] = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- rs GEMM --------------------------------------------------------------------------------
+    {
+      const f32x4* al = As + hl * 32 + l31;
+      for (int g0 = 0; g0 < G; g0 += DR) {
+#pragma unroll
+        for (int d = 0; d < DR; ++d) {
+          const int g = g0 + d;
+          const f32x4 bv = al[g * 2 * 32];
+          f32x4 av[NRT];
+#pragma unroll
+          for (int j = 0; j < NRT; ++j) av[j] = rb[d][j];
+          const int gn = g + DR < G ? g + DR : G - 1;
+#pragma unroll
+          for (int j = 0; j < NRT; ++j)
+            if (j < nact_r) rb[d][j] = bload4(wr_rs, wr_voff, (unsigned)gn * wr_step + j * 2048u);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = 0; j < NRT; ++j)
+              if (j < nact_r) acr[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s4], bv[s4], acr[j], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- stores: h_out = h + rs[:H] (the frame is valid, mask = 1) ; skip (+)= rs[H:] -------------
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) {
+      if (j < nact_r) {
+        const int row0 = (wave + 4 * j) * 32;
+        const bool is_res = !a.last && row0 < H;
+        const unsigned srow0 = (unsigned)(a.last ? row0 : row0 - H);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+          if (is_res) bstore1(acr[j][r], hout_rs, io_voff, (unsigned)(row0 + k) * rowT);
+          else bstore1(acr[j][r], skip_rs, io_voff, (srow0 + k) * rowT);
+        }
+      }
+    }
+  }
+}
+
+bool wn_fused_supported(int H, int K) {
+  return K == kK && H % 32 == 0 && H >= 32 && H <= 192;      // <= 3 row tiles per wave (4 spill)
+}
+
+void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
+  const int G = a.H / 8;
+  const size_t lds_bytes = (size_t)(G * 2 * kXL + G * 2 * 32) * 16;
+  const int nrt = (2 * a.H / 32 + 3) / 4;
+  // at most two resident workgroups per CU (register / LDS budget); a workgroup walks units
+  // blockIdx.x, blockIdx.x + grid, ...; the unit count itself lives on the device
+  long max_units = (long)a.B * ((a.T + kUnit - 1) / kUnit);
+  const int grid = (int)(max_units < 512 ? (max_units < 1 ? 1 : max_units) : 512);
+#define MBV_WN_LAUNCH(N)                                                                          \
+  {                                                                                               \
+    static bool attr = false;                                                                     \
+    if (!attr) {                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wn_layer_kernel<N>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);          \
+      attr = true;                                                                                \
+    }                                                                                             \
+    hipLaunchKernelGGL((wn_layer_kernel<N>), dim3(grid), dim3(256), lds_bytes, s, a);            \
+  }
+  if (nrt <= 2) MBV_WN_LAUNCH(2)
+  else MBV_WN_LAUNCH(3)
+#undef MBV_WN_LAUNCH
+}
+
+}  // namespace mbv
