@@ -89,36 +89,196 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsig
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
 }
 
+// ---- the per-wave pieces.  Every wave always runs its NRT tile slots, with no tests in the MFMA loops
+// (`if (j < nact)` around every MFMA made hipcc emit a branch per instruction).  Slots past the real
+// tile count (only the last layer's 6-tile rs GEMM at H = 192; the small configurations) cost idle
+// MFMAs and nothing else: their weight / bias reads fall outside the buffer ranges or into padding,
+// and their rows lie past H, so the range check of the store drops them.
+struct WnCtx {
+  __amdgpu_buffer_rsrc_t wg_rs, wr_rs, bg_rs, br_rs, gc_rs, hin_rs, hout_rs, skip_rs;
+  unsigned wg_voff, wr_voff, wg_step, wr_step, rowT, io_voff;
+  int G, H, wave, hl, l31, last, skip_accum;
+};
+
+// A ring of the gate GEMM: slot = tap; the load for step s + kDG (s = g * 5 + tap) is issued at step s
+// into the slot step s + kDG - 5 vacated (already consumed), so no value is ever copied and a load has
+// kDG steps (12 MFMAs each) to arrive.  (With the obvious "reload the slot just read" form hipcc sank
+// every load behind the MFMAs that read the old value and then waited for it at the end of the
+// iteration: the whole L2 latency exposed once per channel group.)
+constexpr int kDG = 3;
+template <int NRT>
+__device__ __forceinline__ void gate_ring_init(f32x4 (&ra)[kK][NRT], const WnCtx& c) {
+#pragma unroll
+  for (int tap = 0; tap < kDG; ++tap)
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) ra[tap][j] = bload4(c.wg_rs, c.wg_voff, (unsigned)(tap * c.G) * c.wg_step + j * 2048u);
+}
+
+// gate accumulators start from bias (+ speaker conditioning).  Packed row (r, hl) of tile
+// `wave + 4 j`: registers 0-3 / 8-11 tanh, 4-7 / 12-15 sigmoid of channel 16 tile + (r & 3) + 8 (r >> 3) + 4 hl
+template <int NRT>
+__device__ __forceinline__ void gate_acc_init(f32x16 (&acc)[NRT], const WnCtx& c) {
+  const unsigned vo = (unsigned)(4 * c.hl) * 4u;
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const unsigned so = (unsigned)((c.wave + 4 * j) * 16) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned sr = so + (unsigned)(((r & 3) + 8 * (r >> 3)) * 4) + ((r & 4) ? (unsigned)c.H * 4u : 0u);
+      acc[j][r] = bload1(c.bg_rs, vo, sr) + bload1(c.gc_rs, vo, sr);    // gc_rs is empty without conditioning: reads 0
+    }
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void gate_loop(f32x16 (&acc)[NRT], f32x4 (&ra)[kK][NRT], const f32x4* Xs, const WnCtx& c) {
+  const f32x4* xl = Xs + c.hl * kXL + c.l31;
+  const int G = c.G;
+  f32x4 bv = xl[0];
+  for (int g = 0; g < G; ++g) {
+    const int gn = g + 1 < G ? g + 1 : g;      // past the end: re-load the last group (unused)
+#pragma unroll
+    for (int tap = 0; tap < kK; ++tap) {
+      // A operands of step + kDG into the slot that step vacated kK - kDG steps ago
+      {
+        constexpr int dummy = 0; (void)dummy;
+        const int tl = (tap + kDG) % kK;
+        const int gl = tap + kDG < kK ? g : gn;
+#pragma unroll
+        for (int j = 0; j < NRT; ++j) ra[tl][j] = bload4(c.wg_rs, c.wg_voff, (unsigned)(tl * G + gl) * c.wg_step + j * 2048u);
+      }
+      // B operand of the NEXT step, read while this step's MFMAs run
+      const f32x4 bn = tap + 1 < kK ? xl[g * 2 * kXL + tap + 1] : xl[gn * 2 * kXL];
+      __builtin_amdgcn_sched_barrier(0);       // keep the prefetches HERE (hipcc sinks them to their first use otherwise)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < NRT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[tap][j][s4], bv[s4], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bv = bn;
+    }
+  }
+}
+
+// gating; the gated tile goes to LDS as the B image of the rs GEMM
+template <int NRT>
+__device__ __forceinline__ void gate_act(const f32x16 (&acc)[NRT], f32x4* As, const WnCtx& c) {
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int tile = c.wave + 4 * j;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = tanhf(acc[j][8 * q + s]) * sigmoid_(acc[j][8 * q + s + 4]);
+      if (2 * tile + q < c.G) As[((2 * tile + q) * 2 + c.hl) * 32 + c.l31] = v;   // channels 16 tile + 8 q + 4 hl + s
+    }
+  }
+}
+
+constexpr int kDR = 4;           // slots of the rs GEMM's A ring; loads run kDR - 1 steps ahead
+template <int NRT>
+__device__ __forceinline__ void rs_ring_init(f32x4 (&rb)[kDR][NRT], const WnCtx& c) {
+#pragma unroll
+  for (int d = 0; d < kDR - 1; ++d)
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) rb[d][j] = bload4(c.wr_rs, c.wr_voff, (unsigned)d * c.wr_step + j * 2048u);
+}
+
+// rs accumulators start from bias + what the layer updates in place; rows of tile `wave + 4 j`:
+// (r & 3) + 8 (r >> 2) + 4 hl; frames past the utterance (io_voff out of range) read 0
+template <int NRT>
+__device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const WnCtx& c) {
+  const unsigned bvo = (unsigned)(4 * c.hl) * 4u;
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int row0 = (c.wave + 4 * j) * 32;
+    const bool is_res = !c.last && row0 < c.H;                  // wave-uniform (H % 32 == 0)
+    const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+      float v = bload1(c.br_rs, bvo, (unsigned)(row0 + k) * 4u);
+      if (is_res) v += bload1(c.hin_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
+      else if (c.skip_accum) v += bload1(c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+      acr[j][r] = v;
+    }
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void rs_loop(f32x16 (&acr)[NRT], f32x4 (&rb)[kDR][NRT], const f32x4* As, const WnCtx& c) {
+  const f32x4* al = As + c.hl * 32 + c.l31;
+  const int G = c.G;
+  f32x4 bv = al[0];
+  for (int g0 = 0; g0 < G; g0 += kDR) {
+#pragma unroll
+    for (int d = 0; d < kDR; ++d) {
+      const int g = g0 + d;
+      {
+        const int gl = g + kDR - 1 < G ? g + kDR - 1 : G - 1;
+#pragma unroll
+        for (int j = 0; j < NRT; ++j) rb[(d + kDR - 1) % kDR][j] = bload4(c.wr_rs, c.wr_voff, (unsigned)gl * c.wr_step + j * 2048u);
+      }
+      const int gb = g + 1 < G ? g + 1 : g;
+      const f32x4 bn = al[gb * 2 * 32];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < NRT; ++j)
+          acr[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[d][j][s4], bv[s4], acr[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bv = bn;
+    }
+  }
+}
+
+// h_out = h + rs[:H] (the frame is valid, mask = 1) ; skip (+)= rs[H:]; masked lanes' stores are dropped
+template <int NRT>
+__device__ __forceinline__ void rs_store(const f32x16 (&acr)[NRT], const WnCtx& c) {
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int row0 = (c.wave + 4 * j) * 32;
+    const bool is_res = !c.last && row0 < c.H;
+    const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+      if (is_res) bstore1(acr[j][r], c.hout_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
+      else bstore1(acr[j][r], c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+    }
+  }
+}
+
 // NRT = row tiles per wave (ceil(2H / 32 / 4)): 3 for H = 192 / 160, 2 for H <= 128
 template <int NRT>
 __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = lane >> 5, l31 = lane & 31;
+  WnCtx c;
+  c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  c.hl = lane >> 5; c.l31 = lane & 31;
   const int H = a.H, T = a.T;
-  const int G = H / 8;                         // 8-channel groups (4 K-steps each)
+  c.H = H; c.G = H / 8; c.last = a.last; c.skip_accum = a.skip_accum;
+  const int G = c.G;                           // 8-channel groups (4 K-steps each)
   f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [G][2][kXL]
   f32x4* const As = Xs + G * 2 * kXL;                        // [G][2][32]
-  const int ntg = 2 * H / 32;                  // gate row tiles
-  const int ntr = a.Mr / 32;                   // res/skip row tiles
-  int nact_g = (ntg - wave + 3) / 4;  nact_g = nact_g > NRT ? NRT : nact_g;   // wave-uniform
-  int nact_r = (ntr - wave + 3) / 4;  nact_r = nact_r > NRT ? NRT : nact_r;
   const int U = a.ustart[a.B];
 
   // packed weights W[step][h][Mpad][4 floats], step = tap * G + g: lane offset + scalar step offset
-  const __amdgpu_buffer_rsrc_t wg_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.wg), 0, kK * H * a.Mg_pad * 4, kRsrcFlags);
-  const __amdgpu_buffer_rsrc_t wr_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.wr), 0, H * a.Mr_pad * 4, kRsrcFlags);
-  const __amdgpu_buffer_rsrc_t bg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bg), 0, 2 * H * 4, kRsrcFlags);
-  const __amdgpu_buffer_rsrc_t br_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.br), 0, a.Mr * 4, kRsrcFlags);
-  const unsigned wg_voff = (unsigned)((hl * a.Mg_pad + wave * 32 + l31) * 16);
-  const unsigned wr_voff = (unsigned)((hl * a.Mr_pad + wave * 32 + l31) * 16);
-  const unsigned wg_step = (unsigned)(2 * a.Mg_pad * 16), wr_step = (unsigned)(2 * a.Mr_pad * 16);
-  const unsigned rowT = (unsigned)T * 4u;      // bytes between channel rows of h / skip
-  const unsigned utt_bytes = (unsigned)H * rowT;
+  c.wg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg), 0, kK * H * a.Mg_pad * 4, kRsrcFlags);
+  c.wr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wr), 0, H * a.Mr_pad * 4, kRsrcFlags);
+  c.bg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bg), 0, 2 * H * 4, kRsrcFlags);
+  c.br_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.br), 0, a.Mr * 4, kRsrcFlags);
+  c.wg_voff = (unsigned)((c.hl * a.Mg_pad + c.wave * 32 + c.l31) * 16);
+  c.wr_voff = (unsigned)((c.hl * a.Mr_pad + c.wave * 32 + c.l31) * 16);
+  c.wg_step = (unsigned)(2 * a.Mg_pad * 16);
+  c.wr_step = (unsigned)(2 * a.Mr_pad * 16);
+  c.rowT = (unsigned)T * 4u;                   // bytes between channel rows of h / skip
+  const unsigned utt_bytes = (unsigned)H * c.rowT;
 
   for (int u = blockIdx.x; u < U; u += gridDim.x) {
     int b;
@@ -133,164 +293,47 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
     const int t0 = (u - a.ustart[b]) * kUnit;
     int len = a.lens[b];
     len = len > T ? T : len;
-    const int t = t0 + l31;                    // this lane's frame
-    const bool tv = t < len;
-    // per-utterance views of h_in / h_out / skip
-    const __amdgpu_buffer_rsrc_t hin_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.h_in) + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t hout_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.h_out + (int64_t)b * H * T, 0, a.last ? 0 : utt_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t skip_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.skip + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t gc_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.gcond) + (a.gcond ? (int64_t)b * a.gcond_bstride : 0), 0, a.gcond ? 2 * H * 4 : 0, kRsrcFlags);
+    const int t = t0 + c.l31;                  // this lane's frame
+    c.io_voff = t < len ? (unsigned)(4 * c.hl * T + t) * 4u : kOob;
+    // per-utterance views of h_in / h_out / skip / conditioning
+    c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in) + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
+    c.hout_rs = __builtin_amdgcn_make_buffer_rsrc(a.h_out + (int64_t)b * H * T, 0, a.last ? 0 : utt_bytes, kRsrcFlags);
+    c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
+    c.gc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcond) + (a.gcond ? (int64_t)b * a.gcond_bstride : 0), 0,
+                                                a.gcond ? 2 * H * 4 : 0, kRsrcFlags);
 
-    // ---- A ring of the gate GEMM: the five taps of group 0 -------------------------------
     f32x4 ra[kK][NRT];
-#pragma unroll
-    for (int tap = 0; tap < kK; ++tap)
-#pragma unroll
-      for (int j = 0; j < NRT; ++j)
-        if (j < nact_g) ra[tap][j] = bload4(wg_rs, wg_voff, (unsigned)(tap * G) * wg_step + j * 2048u);
+    gate_ring_init<NRT>(ra, c);      // the five taps of group 0
 
     __syncthreads();                           // the previous unit's readers of Xs / As are done
     // ---- input window: all H channels x 36 frames, masked, k-interleaved ------------------
     {
       const int items = G * 2 * kXL;
       for (int e = tid; e < items; e += 256) {
-        const int P = e / kXL, c = e - P * kXL;
-        const int ti = t0 - (kK - 1) / 2 + c;
+        const int P = e / kXL, cc = e - P * kXL;
+        const int ti = t0 - (kK - 1) / 2 + cc;
         const unsigned vo = (ti >= 0 && ti < len) ? (unsigned)(((P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
         f32x4 v;
-        v[0] = bload1(hin_rs, vo, 0); v[1] = bload1(hin_rs, vo, 2 * rowT);
-        v[2] = bload1(hin_rs, vo, 4 * rowT); v[3] = bload1(hin_rs, vo, 6 * rowT);
+        v[0] = bload1(c.hin_rs, vo, 0); v[1] = bload1(c.hin_rs, vo, 2 * c.rowT);
+        v[2] = bload1(c.hin_rs, vo, 4 * c.rowT); v[3] = bload1(c.hin_rs, vo, 6 * c.rowT);
         Xs[e] = v;
       }
     }
-    // ---- gate accumulators start from bias (+ speaker conditioning) -------------------------
     f32x16 acc[NRT];
-#pragma unroll
-    for (int j = 0; j < NRT; ++j) {
-      // packed row (r, hl) of tile `wave + 4 j`: registers 0-3 / 8-11 tanh, 4-7 / 12-15 sigmoid of
-      // channel 16 tile + (r & 3) + 8 (r >> 3) + 4 hl
-      const unsigned vo = j < nact_g ? (unsigned)(4 * hl) * 4u : kOob;
-      const unsigned so = (unsigned)((wave + 4 * j) * 16) * 4u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned sr = so + (unsigned)(((r & 3) + 8 * (r >> 3)) * 4) + ((r & 4) ? (unsigned)H * 4u : 0u);
-        acc[j][r] = bload1(bg_rs, vo, sr) + bload1(gc_rs, vo, sr);      // gc_rs is empty without conditioning: reads 0
-      }
-    }
+    gate_acc_init<NRT>(acc, c);
     __syncthreads();
 
-    // ---- gate GEMM ---------------------------------------------------------------------------
-    {
-      const f32x4* xl = Xs + hl * kXL + l31;
-      for (int g = 0; g < G; ++g) {
-        const int gn = g + 1 < G ? g + 1 : g;  // last group re-loads itself (unused)
-#pragma unroll
-        for (int tap = 0; tap < kK; ++tap) {
-          const f32x4 bv = xl[g * 2 * kXL + tap];
-          f32x4 av[NRT];
-#pragma unroll
-          for (int j = 0; j < NRT; ++j) av[j] = ra[tap][j];
-#pragma unroll
-          for (int j = 0; j < NRT; ++j)
-            if (j < nact_g) ra[tap][j] = bload4(wg_rs, wg_voff, (unsigned)(tap * G + gn) * wg_step + j * 2048u);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int j = 0; j < NRT; ++j)
-              if (j < nact_g) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s4], bv[s4], acc[j], 0, 0, 0);
-        }
-      }
-    }
+    gate_loop<NRT>(acc, ra, Xs, c);
 
-    // ---- A ring of the rs GEMM (issued before the gating arithmetic, which hides its latency) ----
-    constexpr int DR = 4;
-    f32x4 rb[DR][NRT];
-#pragma unroll
-    for (int d = 0; d < DR; ++d)
-#pragma unroll
-      for (int j = 0; j < NRT; ++j)
-        if (j < nact_r) rb[d][j] = bload4(wr_rs, wr_voff, (unsigned)d * wr_step + j * 2048u);
-
-    // ---- gating, gated tile -> LDS as the B image of the rs GEMM ------------------------------
-#pragma unroll
-    for (int j = 0; j < NRT; ++j) {
-      if (j < nact_g) {
-        const int tile = wave + 4 * j;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          f32x4 v;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) v[s] = tanhf(acc[j][8 * q + s]) * sigmoid_(acc[j][8 * q + s + 4]);
-          As[((2 * tile + q) * 2 + hl) * 32 + l31] = v;        // channels 16 tile + 8 q + 4 hl + s
-        }
-      }
-    }
-    // ---- rs accumulators start from bias + what the layer updates in place -------------------
-    // rows of tile `wave + 4 j`: (r & 3) + 8 (r >> 2) + 4 hl; frames past the utterance read 0
+    f32x4 rb[kDR][NRT];
+    rs_ring_init<NRT>(rb, c);        // issued before the gating arithmetic, which hides its latency
+    gate_act<NRT>(acc, As, c);
     f32x16 acr[NRT];
-    const unsigned io_voff = tv ? (unsigned)(4 * hl * T + t) * 4u : kOob;
-#pragma unroll
-    for (int j = 0; j < NRT; ++j) {
-      const int row0 = (wave + 4 * j) * 32;
-      const bool is_res = !a.last && row0 < H;                // wave-uniform (H % 32 == 0)
-      const unsigned srow0 = (unsigned)(a.last ? row0 : row0 - H);
-      const unsigned bvo = j < nact_r ? (unsigned)(4 * hl) * 4u : kOob;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
-        float v = bload1(br_rs, bvo, (unsigned)(row0 + k) * 4u);
-        if (j < nact_r) {
-          if (is_res) v += bload1(hin_rs, io_voff, (unsigned)(row0 + k) * rowT);
-          else if (a.skip_accum) v += bload1(skip_rs, io_voff, (srow0 + k) * rowT);
-        }
-        acr[j][r] = v;
-      }
-    }
+    rs_acc_init<NRT>(acr, c);
     __syncthreads();
 
-    // ---- rs GEMM --------------------------------------------------------------------------------
-    {
-      const f32x4* al = As + hl * 32 + l31;
-      for (int g0 = 0; g0 < G; g0 += DR) {
-#pragma unroll
-        for (int d = 0; d < DR; ++d) {
-          const int g = g0 + d;
-          const f32x4 bv = al[g * 2 * 32];
-          f32x4 av[NRT];
-#pragma unroll
-          for (int j = 0; j < NRT; ++j) av[j] = rb[d][j];
-          const int gn = g + DR < G ? g + DR : G - 1;
-#pragma unroll
-          for (int j = 0; j < NRT; ++j)
-            if (j < nact_r) rb[d][j] = bload4(wr_rs, wr_voff, (unsigned)gn * wr_step + j * 2048u);
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int j = 0; j < NRT; ++j)
-              if (j < nact_r) acr[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][s4], bv[s4], acr[j], 0, 0, 0);
-        }
-      }
-    }
-
-    // ---- stores: h_out = h + rs[:H] (the frame is valid, mask = 1) ; skip (+)= rs[H:] -------------
-#pragma unroll
-    for (int j = 0; j < NRT; ++j) {
-      if (j < nact_r) {
-        const int row0 = (wave + 4 * j) * 32;
-        const bool is_res = !a.last && row0 < H;
-        const unsigned srow0 = (unsigned)(a.last ? row0 : row0 - H);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
-          if (is_res) bstore1(acr[j][r], hout_rs, io_voff, (unsigned)(row0 + k) * rowT);
-          else bstore1(acr[j][r], skip_rs, io_voff, (srow0 + k) * rowT);
-        }
-      }
-    }
+    rs_loop<NRT>(acr, rb, As, c);
+    rs_store<NRT>(acr, c);
   }
 }
 
