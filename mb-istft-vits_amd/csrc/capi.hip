@@ -966,8 +966,19 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
   const bool cond = gvec && gin && cw.present;
   if (cond) launch_cond_gemv(gvec, nullptr, nullptr, m->W(cw.off), m->W(cb.off), gc, B, gin, 2 * H * nl, s);
   const bool small = (long)B * ((T + 31) / 32) < 192;
-  if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && !(m->splitk && small)) {
+  if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small)) {
     launch_wn_units(lens, B, T, ustart, s);
+    if (getenv("MBV_WN_DEBUG")) {
+      std::vector<int> hu(B + 1), hl(B);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(hu.data(), ustart, (B + 1) * sizeof(int), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hl.data(), lens, B * sizeof(int), hipMemcpyDeviceToHost);
+      fprintf(stderr, "wn debug: B=%d T=%d lens", B, T);
+      for (int i = 0; i < B; ++i) fprintf(stderr, " %d", hl[i]);
+      fprintf(stderr, " ustart");
+      for (int i = 0; i <= B; ++i) fprintf(stderr, " %d", hu[i]);
+      fprintf(stderr, "\n");
+    }
     float* hin = hbuf;
     float* hout = acts;
     for (int l = 0; l < nl; ++l) {

@@ -88,7 +88,7 @@ struct WnLayerArgs {
   float* h_out;            // [B, H, T]  != h_in; unused when last
   float* skip;             // [B, H, T]
   const int* lens;         // [B]
-  const int* ustart;       // [B + 1]: launch_wn_units
+  const int* ustart;       // [B + 1]: launch_wn_units (prefix sums of ceil(len / 16))
   const float* wg; const float* bg;
   const float* gcond;      // [B, gcond_bstride] already offset to this layer, or nullptr
   int gcond_bstride;
@@ -100,6 +100,7 @@ struct WnLayerArgs {
   int skip_accum;          // skip += (layers > 0) instead of skip =
 };
 bool wn_fused_supported(int H, int K);
+bool wn_fused_fits(int B, int H, int T);      // h / skip small enough for the kernel's 32-bit offsets
 void launch_wn_units(const int* lens, int B, int T, int* ustart, hipStream_t s);
 void launch_wn_layer(const WnLayerArgs& a, hipStream_t s);
 

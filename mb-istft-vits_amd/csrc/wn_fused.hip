@@ -5,10 +5,14 @@
 //   rs   = W_rs . acts + b_rs                res_skip_layers[l]  192 -> 384 (last layer: -> 192)
 //   h    = (h + rs[:H]) * mask ; skip += rs[H:]                  (last layer: skip += rs)
 //
-// Work unit = 32 consecutive frames of one utterance; only units that hold valid frames
-// (t0 < len[b]) exist — everything the flows / the posterior encoder compute is masked, and every
-// reader of h / skip masks on load, so padded frames are neither computed nor written.  The unit
-// table (prefix sums of ceil(len / 32)) is built once per WN stack by wn_units_kernel.
+// Work unit = one 32-column MFMA tile = TWO half-units of 16 consecutive frames, each of one
+// utterance; only half-units that hold valid frames (t0 < len[b]) exist — everything the flows / the
+// posterior encoder compute is masked, and every reader of h / skip masks on load, so padded frames
+// are neither computed nor written.  Half-units are numbered through the batch (prefix sums of
+// ceil(len / 16), built once per WN stack by wn_units_kernel) and tile u takes numbers 2u and 2u + 1:
+// usually the two halves of 32 consecutive frames, at the end of an utterance its last 16 frames and
+// the first 16 of the next one (a lane's operand addresses are its own anyway).  The batch then
+// costs sum_b ceil(len_b / 16) / 2 tiles instead of sum_b ceil(len_b / 32).
 //
 // A 256-thread workgroup owns one unit at a time; its 4 waves (one per SIMD) split the ROWS:
 //   gate GEMM   [2H x 5H] . [5H x 32]   row tile t (32 packed rows = 16 tanh + 16 sigmoid rows of
@@ -35,12 +39,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int kK = 5;            // WN kernel size of the flows and of enc_q (models.py:646-647)
-constexpr int kUnit = 32;        // frames per unit
-constexpr int kXL = kUnit + kK - 1;
+constexpr int kUnit = 32;        // columns of a tile
+constexpr int kHalf = 16;        // frames per half-unit
+constexpr int kXW = kHalf + kK - 1;   // input window of a half-unit (20 frames)
+constexpr int kXS = 32;               // its column stride in the LDS image: the second half's lanes then read
+                                      // 16 slots of 16 B behind the first half's, i.e. the same banks a
+                                      // contiguous wave would (a stride of 20 is a 2-way ds_read_b128 conflict)
+constexpr int kXL = 2 * kXS;          // columns per (group, parity) row of the LDS image
 __device__ __forceinline__ float sigmoid_(float v) { return 1.f / (1.f + expf(-v)); }
 }  // namespace
 
-// ustart[b] = sum_{b' < b} ceil(len[b'] / 32), ustart[B] = number of units
+// ustart[b] = sum_{b' < b} ceil(len[b'] / 16), ustart[B] = number of half-units
 __global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
   __shared__ int part[256];
   const int tid = threadIdx.x;
@@ -48,7 +57,7 @@ __global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
   int s = 0;
   for (int i = 0; i < per; ++i) {
     const int b = tid * per + i;
-    if (b < B) { int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l); s += (l + kUnit - 1) / kUnit; }
+    if (b < B) { int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l); s += (l + kHalf - 1) / kHalf; }
   }
   part[tid] = s;
   __syncthreads();
@@ -63,7 +72,7 @@ __global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
     if (b < B) {
       ustart[b] = run;
       int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l);
-      run += (l + kUnit - 1) / kUnit;
+      run += (l + kHalf - 1) / kHalf;
       if (b == B - 1) ustart[B] = run;
     }
   }
@@ -92,12 +101,13 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsig
 // ---- the per-wave pieces.  Every wave always runs its NRT tile slots, with no tests in the MFMA loops
 // (`if (j < nact)` around every MFMA made hipcc emit a branch per instruction).  Slots past the real
 // tile count (only the last layer's 6-tile rs GEMM at H = 192; the small configurations) cost idle
-// MFMAs and nothing else: their weight / bias reads fall outside the buffer ranges or into padding,
-// and their rows lie past H, so the range check of the store drops them.
+// MFMAs and nothing else: their weight / bias reads fall outside the buffer ranges or into padding
+// (garbage in, never used), and their loads / stores of h / skip are skipped by a wave-uniform test.
 struct WnCtx {
   __amdgpu_buffer_rsrc_t wg_rs, wr_rs, bg_rs, br_rs, gc_rs, hin_rs, hout_rs, skip_rs;
-  unsigned wg_voff, wr_voff, wg_step, wr_step, rowT, io_voff;
-  int G, H, wave, hl, l31, last, skip_accum;
+  unsigned wg_voff, wr_voff, wg_step, wr_step, rowT, io_voff, gc_voff;
+  int xoff;                      // lane's column in the input-window image: half * kXS + (l31 & 15)
+  int G, H, Mr, wave, hl, l31, last, skip_accum;
 };
 
 // A ring of the gate GEMM: slot = tap; the load for step s + kDG (s = g * 5 + tap) is issued at step s
@@ -125,14 +135,14 @@ __device__ __forceinline__ void gate_acc_init(f32x16 (&acc)[NRT], const WnCtx& c
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned sr = so + (unsigned)(((r & 3) + 8 * (r >> 3)) * 4) + ((r & 4) ? (unsigned)c.H * 4u : 0u);
-      acc[j][r] = bload1(c.bg_rs, vo, sr) + bload1(c.gc_rs, vo, sr);    // gc_rs is empty without conditioning: reads 0
+      acc[j][r] = bload1(c.bg_rs, vo, sr) + bload1(c.gc_rs, c.gc_voff, sr);   // gc_rs is empty without conditioning: reads 0
     }
   }
 }
 
 template <int NRT>
 __device__ __forceinline__ void gate_loop(f32x16 (&acc)[NRT], f32x4 (&ra)[kK][NRT], const f32x4* Xs, const WnCtx& c) {
-  const f32x4* xl = Xs + c.hl * kXL + c.l31;
+  const f32x4* xl = Xs + c.hl * kXL + c.xoff;
   const int G = c.G;
   f32x4 bv = xl[0];
   for (int g = 0; g < G; ++g) {
@@ -200,8 +210,10 @@ __device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const WnCtx& c) 
     for (int r = 0; r < 16; ++r) {
       const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
       float v = bload1(c.br_rs, bvo, (unsigned)(row0 + k) * 4u);
-      if (is_res) v += bload1(c.hin_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
-      else if (c.skip_accum) v += bload1(c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+      if (row0 < c.Mr) {                                        // (an idle tile slot: see rs_store)
+        if (is_res) v += bload1(c.hin_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
+        else if (c.skip_accum) v += bload1(c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+      }
       acr[j][r] = v;
     }
   }
@@ -241,6 +253,9 @@ __device__ __forceinline__ void rs_store(const f32x16 (&acr)[NRT], const WnCtx& 
 #pragma unroll
   for (int j = 0; j < NRT; ++j) {
     const int row0 = (c.wave + 4 * j) * 32;
+    // an idle tile slot (rows past Mr: the last layer's 6-tile rs GEMM, the small configurations) must
+    // not store: h / skip are whole-tensor views, rows past H would land in the NEXT utterance
+    if (row0 >= c.Mr) continue;
     const bool is_res = !c.last && row0 < c.H;
     const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
 #pragma unroll
@@ -262,11 +277,12 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.hl = lane >> 5; c.l31 = lane & 31;
   const int H = a.H, T = a.T;
-  c.H = H; c.G = H / 8; c.last = a.last; c.skip_accum = a.skip_accum;
+  c.H = H; c.G = H / 8; c.Mr = a.Mr; c.last = a.last; c.skip_accum = a.skip_accum;
   const int G = c.G;                           // 8-channel groups (4 K-steps each)
   f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [G][2][kXL]
   f32x4* const As = Xs + G * 2 * kXL;                        // [G][2][32]
-  const int U = a.ustart[a.B];
+  const int Hn = a.ustart[a.B];                // half-units of the batch
+  const int U = (Hn + 1) / 2;                  // tiles
 
   // packed weights W[step][h][Mpad][4 floats], step = tap * G + g: lane offset + scalar step offset
   c.wg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg), 0, kK * H * a.Mg_pad * 4, kRsrcFlags);
@@ -278,41 +294,56 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   c.wg_step = (unsigned)(2 * a.Mg_pad * 16);
   c.wr_step = (unsigned)(2 * a.Mr_pad * 16);
   c.rowT = (unsigned)T * 4u;                   // bytes between channel rows of h / skip
-  const unsigned utt_bytes = (unsigned)H * c.rowT;
+  // whole-tensor views (the launcher checks B H T 4 < 2^32): the two halves of a tile may belong to
+  // different utterances, so the utterance goes into the lane offset
+  const unsigned all_bytes = (unsigned)a.B * (unsigned)H * c.rowT;
+  c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in), 0, all_bytes, kRsrcFlags);
+  c.hout_rs = __builtin_amdgcn_make_buffer_rsrc(a.h_out, 0, a.last ? 0 : all_bytes, kRsrcFlags);
+  c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip, 0, all_bytes, kRsrcFlags);
+  c.gc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcond), 0, a.gcond ? a.B * a.gcond_bstride * 4 : 0, kRsrcFlags);
+  const int half = c.l31 >> 4, jl = c.l31 & 15;
+  c.xoff = half * kXS + jl;
 
   for (int u = blockIdx.x; u < U; u += gridDim.x) {
-    int b;
-    {
-      int lo = 0, hi = a.B - 1;                // largest b with ustart[b] <= u
+    // the two half-units of this tile: utterance, first frame, utterance length (0: no such half-unit)
+    int hb[2], ht0[2], hlen[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hu = 2 * u + k;
+      int lo = 0, hi = a.B - 1;                // largest b with ustart[b] <= hu
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (a.ustart[mid] <= u) lo = mid; else hi = mid - 1;
+        if (a.ustart[mid] <= hu) lo = mid; else hi = mid - 1;
       }
-      b = lo;
+      hb[k] = lo;
+      ht0[k] = (hu - a.ustart[lo]) * kHalf;
+      int len = a.lens[lo];
+      len = len > T ? T : len;
+      hlen[k] = hu < Hn ? len : 0;
     }
-    const int t0 = (u - a.ustart[b]) * kUnit;
-    int len = a.lens[b];
-    len = len > T ? T : len;
-    const int t = t0 + c.l31;                  // this lane's frame
-    c.io_voff = t < len ? (unsigned)(4 * c.hl * T + t) * 4u : kOob;
-    // per-utterance views of h_in / h_out / skip / conditioning
-    c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in) + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
-    c.hout_rs = __builtin_amdgcn_make_buffer_rsrc(a.h_out + (int64_t)b * H * T, 0, a.last ? 0 : utt_bytes, kRsrcFlags);
-    c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip + (int64_t)b * H * T, 0, utt_bytes, kRsrcFlags);
-    c.gc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcond) + (a.gcond ? (int64_t)b * a.gcond_bstride : 0), 0,
-                                                a.gcond ? 2 * H * 4 : 0, kRsrcFlags);
+    {
+      const int b = half ? hb[1] : hb[0];
+      const int t = (half ? ht0[1] : ht0[0]) + jl;          // this lane's frame
+      const bool tv = t < (half ? hlen[1] : hlen[0]);
+      c.io_voff = tv ? (unsigned)((b * H + 4 * c.hl) * T + t) * 4u : kOob;
+      c.gc_voff = (unsigned)(b * a.gcond_bstride + 4 * c.hl) * 4u;
+    }
 
     f32x4 ra[kK][NRT];
     gate_ring_init<NRT>(ra, c);      // the five taps of group 0
 
     __syncthreads();                           // the previous unit's readers of Xs / As are done
-    // ---- input window: all H channels x 36 frames, masked, k-interleaved ------------------
+    // ---- input windows: all H channels x 2 x 20 frames, masked, k-interleaved ----------------
     {
       const int items = G * 2 * kXL;
       for (int e = tid; e < items; e += 256) {
         const int P = e / kXL, cc = e - P * kXL;
-        const int ti = t0 - (kK - 1) / 2 + cc;
-        const unsigned vo = (ti >= 0 && ti < len) ? (unsigned)(((P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
+        const int k = cc >= kXS, c2 = cc - k * kXS;
+        if (c2 >= kXW) continue;               // stride padding, never read
+        const int ti = (k ? ht0[1] : ht0[0]) - (kK - 1) / 2 + c2;
+        const int b = k ? hb[1] : hb[0];
+        const unsigned vo = (ti >= 0 && ti < (k ? hlen[1] : hlen[0]))
+                                ? (unsigned)((b * H + (P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
         f32x4 v;
         v[0] = bload1(c.hin_rs, vo, 0); v[1] = bload1(c.hin_rs, vo, 2 * c.rowT);
         v[2] = bload1(c.hin_rs, vo, 4 * c.rowT); v[3] = bload1(c.hin_rs, vo, 6 * c.rowT);
@@ -337,6 +368,9 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   }
 }
 
+// (the kernel addresses h / skip through whole-tensor buffer views: B * H * T * 4 must stay below 2^32)
+bool wn_fused_fits(int B, int H, int T) { return (unsigned long long)B * H * T * 4ull < (1ull << 32); }
+
 bool wn_fused_supported(int H, int K) {
   return K == kK && H % 32 == 0 && H >= 32 && H <= 192;      // <= 3 row tiles per wave (4 spill)
 }
@@ -347,7 +381,7 @@ void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
   const int nrt = (2 * a.H / 32 + 3) / 4;
   // at most two resident workgroups per CU (register / LDS budget); a workgroup walks units
   // blockIdx.x, blockIdx.x + grid, ...; the unit count itself lives on the device
-  long max_units = (long)a.B * ((a.T + kUnit - 1) / kUnit);
+  long max_units = ((long)a.B * ((a.T + kHalf - 1) / kHalf) + 1) / 2;
   const int grid = (int)(max_units < 512 ? (max_units < 1 ? 1 : max_units) : 512);
 #define MBV_WN_LAUNCH(N)                                                                          \
   {                                                                                               \
