@@ -967,23 +967,13 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
   if (cond) launch_cond_gemv(gvec, nullptr, nullptr, m->W(cw.off), m->W(cb.off), gc, B, gin, 2 * H * nl, s);
   const bool small = (long)B * ((T + 31) / 32) < 192;
   if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small)) {
-    launch_wn_units(lens, B, T, ustart, s);
-    if (getenv("MBV_WN_DEBUG")) {
-      std::vector<int> hu(B + 1), hl(B);
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpy(hu.data(), ustart, (B + 1) * sizeof(int), hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hl.data(), lens, B * sizeof(int), hipMemcpyDeviceToHost);
-      fprintf(stderr, "wn debug: B=%d T=%d lens", B, T);
-      for (int i = 0; i < B; ++i) fprintf(stderr, " %d", hl[i]);
-      fprintf(stderr, " ustart");
-      for (int i = 0; i <= B; ++i) fprintf(stderr, " %d", hu[i]);
-      fprintf(stderr, "\n");
-    }
+    int* hmap = ustart + B + 1;
+    launch_wn_units(lens, B, T, ustart, hmap, s);
     float* hin = hbuf;
     float* hout = acts;
     for (int l = 0; l < nl; ++l) {
       WnLayerArgs a{};
-      a.h_in = hin; a.h_out = hout; a.skip = skip; a.lens = lens; a.ustart = ustart;
+      a.h_in = hin; a.h_out = hout; a.skip = skip; a.lens = lens; a.ustart = ustart; a.hmap = hmap;
       a.wg = m->W(in16_l[l].w); a.bg = m->W(in16_l[l].bias);
       if (cond) { a.gcond = gc + (size_t)l * 2 * H; a.gcond_bstride = 2 * H * nl; }
       a.wr = m->W(rsp_l[l].w); a.br = m->W(rsp_l[l].bias);
@@ -1363,7 +1353,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   const int Td = (max_len > 0 && max_len < Tp) ? max_len : Tp;
   const size_t BTp = (size_t)B * Tp;
   const bool run_dec = outs && (outs->o || outs->o_mb || outs->spec || outs->phase);
-  size_t need = (BTp * (4 * I + 3 * H) + (size_t)B * (2 * H * kFlowLayers + 2)) * 4 + 64 * 256 +
+  size_t need = (BTp * (4 * I + 3 * H) + (size_t)B * (2 * H * kFlowLayers + 2)) * 4 + wn_units_ints(B, Tp) * 4 + 64 * 256 +
                 decoder_scratch_bytes(c, B, Td);
   if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
   Bump sc{m->scrB, m->scrB_bytes};
@@ -1374,7 +1364,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   float* acts = sc.take<float>(BTp * H);
   float* skip = sc.take<float>(BTp * H);
   float* gc = sc.take<float>((size_t)B * 2 * H * kFlowLayers);
-  int* ustart = sc.take<int>((size_t)B + 1);
+  int* ustart = sc.take<int>(wn_units_ints(B, Tp));
   (void)gin;
 
   HIPCHK(m, hipEventRecord(m->ev[3], s));
@@ -1485,7 +1475,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
   const int H = c.hidden_channels, I = c.inter_channels, gin = c.gin_channels, SC = c.spec_channels;
   const auto& Q = m->encq;
   const size_t BT = (size_t)B * T;
-  size_t need = (BT * ((size_t)Q.cin_pad + 3 * H + 4 * I) + (size_t)B * (2 * gin + 2 * H * mbv_model::kEncQLayers + 18)) * 4 +
+  size_t need = (BT * ((size_t)Q.cin_pad + 3 * H + 4 * I) + (size_t)B * (2 * gin + 2 * H * mbv_model::kEncQLayers + 18)) * 4 + wn_units_ints(B, T) * 4 +
                 64 * 256 + decoder_scratch_bytes(c, B, T);
   if (ensure(m, &m->scrB, &m->scrB_bytes, need)) return 1;
   Bump sc{m->scrB, m->scrB_bytes};
@@ -1502,7 +1492,7 @@ int mbv_voice_conversion(mbv_model* m, const float* y, const int64_t* y_lengths,
   float* gc = sc.take<float>((size_t)B * 2 * H * mbv_model::kEncQLayers);
   int* lens = sc.take<int>(B);
   int* bad = sc.take<int>(B);
-  int* ustart = sc.take<int>((size_t)B + 1);
+  int* ustart = sc.take<int>(wn_units_ints(B, T));
 
   launch_lens_to_i32(y_lengths, lens, B, T, bad, s);
   launch_gather_rows(m->W(m->emb_g.off), sid_src, g_src, B, gin, c.n_speakers, bad, s);

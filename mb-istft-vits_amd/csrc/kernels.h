@@ -89,6 +89,7 @@ struct WnLayerArgs {
   float* skip;             // [B, H, T]
   const int* lens;         // [B]
   const int* ustart;       // [B + 1]: launch_wn_units (prefix sums of ceil(len / 16))
+  const int* hmap;         // [ustart[B] + 1]: utterance of every half-unit
   const float* wg; const float* bg;
   const float* gcond;      // [B, gcond_bstride] already offset to this layer, or nullptr
   int gcond_bstride;
@@ -98,10 +99,13 @@ struct WnLayerArgs {
   int Mr, Mr_pad;          // rows of the res/skip conv (2H, or H for the last layer)
   int last;                // Mr == H: every row goes to skip
   int skip_accum;          // skip += (layers > 0) instead of skip =
+  int debug;               // set by the launcher (MBV_WN_DEBUG_A): timing experiments, results wrong by design
 };
 bool wn_fused_supported(int H, int K);
 bool wn_fused_fits(int B, int H, int T);      // h / skip small enough for the kernel's 32-bit offsets
-void launch_wn_units(const int* lens, int B, int T, int* ustart, hipStream_t s);
+// `ustart` points at wn_units_ints(B, T) ints: [B + 1] prefix sums, then the half-unit -> utterance map
+size_t wn_units_ints(int B, int T);
+void launch_wn_units(const int* lens, int B, int T, int* ustart, int* hmap, hipStream_t s);
 void launch_wn_layer(const WnLayerArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- ConvTranspose1d k=16, stride 4 / 8 (MFMA)

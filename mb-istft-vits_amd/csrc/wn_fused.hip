@@ -46,11 +46,22 @@ constexpr int kXS = 32;               // its column stride in the LDS image: the
                                       // 16 slots of 16 B behind the first half's, i.e. the same banks a
                                       // contiguous wave would (a stride of 20 is a 2-way ds_read_b128 conflict)
 constexpr int kXL = 2 * kXS;          // columns per (group, parity) row of the LDS image
+// tanh(x) * sigmoid(y) on the hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp each):
+//   sigmoid(y) = 1 / (1 + 2^(-y log2 e)),  tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e))
+// absolute error ~1e-7 (the libm forms cost ~100 instructions per gated value; 24 values per lane and tile)
+__device__ __forceinline__ float gate_fast(float x, float y) {
+  const float e2x = __builtin_amdgcn_exp2f(x * 2.88539008177792681f);
+  const float emy = __builtin_amdgcn_exp2f(y * -1.44269504088896341f);
+  const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e2x);
+  return th * __builtin_amdgcn_rcpf(1.f + emy);
+}
 __device__ __forceinline__ float sigmoid_(float v) { return 1.f / (1.f + expf(-v)); }
 }  // namespace
 
-// ustart[b] = sum_{b' < b} ceil(len[b'] / 16), ustart[B] = number of half-units
-__global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
+// ustart[b] = sum_{b' < b} ceil(len[b'] / 16), ustart[B] = number of half-units;
+// hmap[hu] = utterance of half-unit hu (so that a tile finds its two utterances with one dependent
+// load each instead of a binary search of ~log2 B dependent loads: 12 L2 round trips per tile at B = 64)
+__global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart, int* hmap) {
   __shared__ int part[256];
   const int tid = threadIdx.x;
   const int per = (B + 255) / 256;
@@ -72,15 +83,19 @@ __global__ void wn_units_kernel(const int* lens, int B, int T, int* ustart) {
     if (b < B) {
       ustart[b] = run;
       int l = lens[b]; l = l < 0 ? 0 : (l > T ? T : l);
-      run += (l + kHalf - 1) / kHalf;
-      if (b == B - 1) ustart[B] = run;
+      const int n = (l + kHalf - 1) / kHalf;
+      for (int k = 0; k < n; ++k) hmap[run + k] = b;
+      run += n;
+      if (b == B - 1) { ustart[B] = run; hmap[run] = b; }     // one entry past the end: the odd tile's second half
     }
   }
 }
 
-void launch_wn_units(const int* lens, int B, int T, int* ustart, hipStream_t s) {
-  hipLaunchKernelGGL(wn_units_kernel, dim3(1), dim3(256), 0, s, lens, B, T, ustart);
+void launch_wn_units(const int* lens, int B, int T, int* ustart, int* hmap, hipStream_t s) {
+  hipLaunchKernelGGL(wn_units_kernel, dim3(1), dim3(256), 0, s, lens, B, T, ustart, hmap);
 }
+
+size_t wn_units_ints(int B, int T) { return (size_t)B + 1 + (size_t)B * ((T + kHalf - 1) / kHalf) + 1; }
 
 // raw buffer access: one 32-bit lane offset per tensor, every row / step stride rides in a scalar
 // register (64-bit per-access pointers made the unrolled loads below spill); out-of-range lanes read 0
@@ -107,7 +122,7 @@ struct WnCtx {
   __amdgpu_buffer_rsrc_t wg_rs, wr_rs, bg_rs, br_rs, gc_rs, hin_rs, hout_rs, skip_rs;
   unsigned wg_voff, wr_voff, wg_step, wr_step, rowT, io_voff, gc_voff;
   int xoff;                      // lane's column in the input-window image: half * kXS + (l31 & 15)
-  int G, H, Mr, wave, hl, l31, last, skip_accum;
+  int G, H, Mr, wave, hl, l31, last, skip_accum, exact_gate;
 };
 
 // A ring of the gate GEMM: slot = tap; the load for step s + kDG (s = g * 5 + tap) is issued at step s
@@ -115,7 +130,7 @@ struct WnCtx {
 // kDG steps (12 MFMAs each) to arrive.  (With the obvious "reload the slot just read" form hipcc sank
 // every load behind the MFMAs that read the old value and then waited for it at the end of the
 // iteration: the whole L2 latency exposed once per channel group.)
-constexpr int kDG = 3;
+constexpr int kDG = 4;
 template <int NRT>
 __device__ __forceinline__ void gate_ring_init(f32x4 (&ra)[kK][NRT], const WnCtx& c) {
 #pragma unroll
@@ -125,17 +140,21 @@ __device__ __forceinline__ void gate_ring_init(f32x4 (&ra)[kK][NRT], const WnCtx
 }
 
 // gate accumulators start from bias (+ speaker conditioning).  Packed row (r, hl) of tile
-// `wave + 4 j`: registers 0-3 / 8-11 tanh, 4-7 / 12-15 sigmoid of channel 16 tile + (r & 3) + 8 (r >> 3) + 4 hl
+// `wave + 4 j`: registers 0-3 / 8-11 tanh, 4-7 / 12-15 sigmoid of channel 16 tile + (r & 3) + 8 (r >> 3) + 4 hl:
+// every group of four registers is four consecutive channels = one 16-byte load
 template <int NRT>
-__device__ __forceinline__ void gate_acc_init(f32x16 (&acc)[NRT], const WnCtx& c) {
+__device__ __forceinline__ void gate_acc_init(f32x16 (&acc)[NRT], const WnCtx& c, bool cond) {
   const unsigned vo = (unsigned)(4 * c.hl) * 4u;
 #pragma unroll
   for (int j = 0; j < NRT; ++j) {
     const unsigned so = (unsigned)((c.wave + 4 * j) * 16) * 4u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned sr = so + (unsigned)(((r & 3) + 8 * (r >> 3)) * 4) + ((r & 4) ? (unsigned)c.H * 4u : 0u);
-      acc[j][r] = bload1(c.bg_rs, vo, sr) + bload1(c.gc_rs, c.gc_voff, sr);   // gc_rs is empty without conditioning: reads 0
+    for (int q = 0; q < 4; ++q) {
+      const unsigned sr = so + (unsigned)(8 * (q >> 1)) * 4u + ((q & 1) ? (unsigned)c.H * 4u : 0u);
+      f32x4 v = bload4(c.bg_rs, vo, sr);
+      if (cond) v += bload4(c.gc_rs, c.gc_voff, sr);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[j][4 * q + s] = v[s];
     }
   }
 }
@@ -181,7 +200,8 @@ __device__ __forceinline__ void gate_act(const f32x16 (&acc)[NRT], f32x4* As, co
     for (int q = 0; q < 2; ++q) {
       f32x4 v;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = tanhf(acc[j][8 * q + s]) * sigmoid_(acc[j][8 * q + s + 4]);
+      for (int s = 0; s < 4; ++s)
+        v[s] = c.exact_gate ? tanhf(acc[j][8 * q + s]) * sigmoid_(acc[j][8 * q + s + 4]) : gate_fast(acc[j][8 * q + s], acc[j][8 * q + s + 4]);
       if (2 * tile + q < c.G) As[((2 * tile + q) * 2 + c.hl) * 32 + c.l31] = v;   // channels 16 tile + 8 q + 4 hl + s
     }
   }
@@ -197,24 +217,35 @@ __device__ __forceinline__ void rs_ring_init(f32x4 (&rb)[kDR][NRT], const WnCtx&
 }
 
 // rs accumulators start from bias + what the layer updates in place; rows of tile `wave + 4 j`:
-// (r & 3) + 8 (r >> 2) + 4 hl; frames past the utterance (io_voff out of range) read 0
+// (r & 3) + 8 (r >> 2) + 4 hl.  The residual rows' start values (h of the tile's own frames) are
+// already in LDS: the centre of the input window (channel ch -> image row (ch / 8) * 2 + (ch & 1),
+// component (ch & 7) >> 1); masked frames hold 0 there.  skip comes from memory (masked lanes read 0).
 template <int NRT>
-__device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const WnCtx& c) {
+__device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const f32x4* Xs, const WnCtx& c) {
   const unsigned bvo = (unsigned)(4 * c.hl) * 4u;
+  const float* xc = reinterpret_cast<const float*>(Xs + c.xoff + (kK - 1) / 2);
 #pragma unroll
   for (int j = 0; j < NRT; ++j) {
     const int row0 = (c.wave + 4 * j) * 32;
     const bool is_res = !c.last && row0 < c.H;                  // wave-uniform (H % 32 == 0)
     const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
-      float v = bload1(c.br_rs, bvo, (unsigned)(row0 + k) * 4u);
-      if (row0 < c.Mr) {                                        // (an idle tile slot: see rs_store)
-        if (is_res) v += bload1(c.hin_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
-        else if (c.skip_accum) v += bload1(c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = bload4(c.br_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int r = 4 * q + s;
+        float v = bq[s];
+        if (row0 < c.Mr) {                                      // (an idle tile slot: see rs_store)
+          if (is_res) {
+            const int ch = row0 + 8 * q + 4 * c.hl + s;         // (ch & 7) = 4 hl + s
+            v += xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
+          } else if (c.skip_accum) {
+            v += bload1(c.skip_rs, c.io_voff, (srow0 + 8 * q + s) * c.rowT);
+          }
+        }
+        acr[j][r] = v;
       }
-      acr[j][r] = v;
     }
   }
 }
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   c.hl = lane >> 5; c.l31 = lane & 31;
   const int H = a.H, T = a.T;
-  c.H = H; c.G = H / 8; c.Mr = a.Mr; c.last = a.last; c.skip_accum = a.skip_accum;
+  c.H = H; c.G = H / 8; c.Mr = a.Mr; c.last = a.last; c.skip_accum = a.skip_accum; c.exact_gate = a.debug == 2;
   const int G = c.G;                           // 8-channel groups (4 K-steps each)
   f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [G][2][kXL]
   f32x4* const As = Xs + G * 2 * kXL;                        // [G][2][32]
@@ -291,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   c.br_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.br), 0, a.Mr * 4, kRsrcFlags);
   c.wg_voff = (unsigned)((c.hl * a.Mg_pad + c.wave * 32 + c.l31) * 16);
   c.wr_voff = (unsigned)((c.hl * a.Mr_pad + c.wave * 32 + c.l31) * 16);
-  c.wg_step = (unsigned)(2 * a.Mg_pad * 16);
-  c.wr_step = (unsigned)(2 * a.Mr_pad * 16);
+  c.wg_step = a.debug == 1 ? 0u : (unsigned)(2 * a.Mg_pad * 16);
+  c.wr_step = a.debug == 1 ? 0u : (unsigned)(2 * a.Mr_pad * 16);
   c.rowT = (unsigned)T * 4u;                   // bytes between channel rows of h / skip
   // whole-tensor views (the launcher checks B H T 4 < 2^32): the two halves of a tile may belong to
   // different utterances, so the utterance goes into the lane offset
@@ -310,11 +341,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int hu = 2 * u + k;
-      int lo = 0, hi = a.B - 1;                // largest b with ustart[b] <= hu
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a.ustart[mid] <= hu) lo = mid; else hi = mid - 1;
-      }
+      const int lo = a.hmap[hu];               // (hu <= Hn: the map has one entry past the end)
       hb[k] = lo;
       ht0[k] = (hu - a.ustart[lo]) * kHalf;
       int len = a.lens[lo];
@@ -330,37 +357,42 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
     }
 
     f32x4 ra[kK][NRT];
-    gate_ring_init<NRT>(ra, c);      // the five taps of group 0
+    gate_ring_init<NRT>(ra, c);      // the first kDG steps of the A ring
 
-    __syncthreads();                           // the previous unit's readers of Xs / As are done
-    // ---- input windows: all H channels x 2 x 20 frames, masked, k-interleaved ----------------
-    {
-      const int items = G * 2 * kXL;
-      for (int e = tid; e < items; e += 256) {
-        const int P = e / kXL, cc = e - P * kXL;
-        const int k = cc >= kXS, c2 = cc - k * kXS;
-        if (c2 >= kXW) continue;               // stride padding, never read
-        const int ti = (k ? ht0[1] : ht0[0]) - (kK - 1) / 2 + c2;
-        const int b = k ? hb[1] : hb[0];
-        const unsigned vo = (ti >= 0 && ti < (k ? hlen[1] : hlen[0]))
-                                ? (unsigned)((b * H + (P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
-        f32x4 v;
-        v[0] = bload1(c.hin_rs, vo, 0); v[1] = bload1(c.hin_rs, vo, 2 * c.rowT);
-        v[2] = bload1(c.hin_rs, vo, 4 * c.rowT); v[3] = bload1(c.hin_rs, vo, 6 * c.rowT);
-        Xs[e] = v;
-      }
+    // ---- input windows: all H channels x 2 x 20 frames, masked, k-interleaved.  Every load of the
+    // tile's prologue (ring, windows, bias) is issued before the first wait: one memory latency
+    // instead of one per staging pass.
+    constexpr int NXI = NRT == 3 ? 12 : 8;     // window items per thread (G * 2 * kXL / 256, G <= 8 NRT)
+    f32x4 xw[NXI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int e = tid + 256 * i;
+      const int P = e / kXL, cc = e - P * kXL;
+      const int k = cc >= kXS, c2 = cc - k * kXS;
+      const int ti = (k ? ht0[1] : ht0[0]) - (kK - 1) / 2 + c2;
+      const int b = k ? hb[1] : hb[0];
+      const bool ok = P < 2 * G && c2 < kXW && ti >= 0 && ti < (k ? hlen[1] : hlen[0]);
+      const unsigned vo = ok ? (unsigned)((b * H + (P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
+      xw[i][0] = bload1(c.hin_rs, vo, 0); xw[i][1] = bload1(c.hin_rs, vo, 2 * c.rowT);
+      xw[i][2] = bload1(c.hin_rs, vo, 4 * c.rowT); xw[i][3] = bload1(c.hin_rs, vo, 6 * c.rowT);
     }
     f32x16 acc[NRT];
-    gate_acc_init<NRT>(acc, c);
+    gate_acc_init<NRT>(acc, c, a.gcond != nullptr);
+    __syncthreads();                           // the previous tile's readers of Xs / As are done
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int e = tid + 256 * i;
+      if (e < G * 2 * kXL) Xs[e] = xw[i];
+    }
     __syncthreads();
 
     gate_loop<NRT>(acc, ra, Xs, c);
 
     f32x4 rb[kDR][NRT];
-    rs_ring_init<NRT>(rb, c);        // issued before the gating arithmetic, which hides its latency
-    gate_act<NRT>(acc, As, c);
+    rs_ring_init<NRT>(rb, c);        // both issued before the gating arithmetic, which hides their latency
     f32x16 acr[NRT];
-    rs_acc_init<NRT>(acr, c);
+    rs_acc_init<NRT>(acr, Xs, c);
+    gate_act<NRT>(acc, As, c);
     __syncthreads();
 
     rs_loop<NRT>(acr, rb, As, c);
@@ -379,10 +411,15 @@ void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
   const int G = a.H / 8;
   const size_t lds_bytes = (size_t)(G * 2 * kXL + G * 2 * 32) * 16;
   const int nrt = (2 * a.H / 32 + 3) / 4;
+  WnLayerArgs a2 = a;
+  static const int dbg = [] { const char* e = getenv("MBV_WN_DEBUG_A"); return e ? atoi(e) : 0; }();
+  a2.debug = dbg;                    // experiments: 1 = every step reads the weights of step 0 (timing only, results wrong);
+                                     // 2 = libm tanhf / expf in the gating instead of the hardware transcendentals
   // at most two resident workgroups per CU (register / LDS budget); a workgroup walks units
   // blockIdx.x, blockIdx.x + grid, ...; the unit count itself lives on the device
   long max_units = ((long)a.B * ((a.T + kHalf - 1) / kHalf) + 1) / 2;
-  const int grid = (int)(max_units < 512 ? (max_units < 1 ? 1 : max_units) : 512);
+  static const int grid_cap = [] { const char* e = getenv("MBV_WN_GRID"); return e ? atoi(e) : 512; }();
+  const int grid = (int)(max_units < grid_cap ? (max_units < 1 ? 1 : max_units) : grid_cap);
 #define MBV_WN_LAUNCH(N)                                                                          \
   {                                                                                               \
     static bool attr = false;                                                                     \
@@ -391,7 +428,7 @@ void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);          \
       attr = true;                                                                                \
     }                                                                                             \
-    hipLaunchKernelGGL((wn_layer_kernel<N>), dim3(grid), dim3(256), lds_bytes, s, a);            \
+    hipLaunchKernelGGL((wn_layer_kernel<N>), dim3(grid), dim3(256), lds_bytes, s, a2);            \
   }
   if (nrt <= 2) MBV_WN_LAUNCH(2)
   else MBV_WN_LAUNCH(3)

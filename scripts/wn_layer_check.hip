@@ -66,16 +66,16 @@ int main(int argc, char** argv) {
   float *d_h, *d_ho, *d_skip, *d_wg, *d_bg, *d_wr, *d_br; int *d_lens, *d_us;
   hipMalloc(&d_h, h.size() * 4); hipMalloc(&d_ho, h.size() * 4); hipMalloc(&d_skip, h.size() * 4);
   hipMalloc(&d_wg, wgp.size() * 4); hipMalloc(&d_bg, bg.size() * 4); hipMalloc(&d_wr, wrp.size() * 4); hipMalloc(&d_br, br.size() * 4);
-  hipMalloc(&d_lens, B * 4); hipMalloc(&d_us, (B + 1) * 4);
+  hipMalloc(&d_lens, B * 4); hipMalloc(&d_us, wn_units_ints(B, T) * 4);
   hipMemcpy(d_h, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemset(d_ho, 0, h.size() * 4);
   hipMemcpy(d_skip, skip0.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_wg, wgp.data(), wgp.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_bg, bg.data(), bg.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_wr, wrp.data(), wrp.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_br, br.data(), br.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_lens, lens.data(), B * 4, hipMemcpyHostToDevice);
-  launch_wn_units(d_lens, B, T, d_us, 0);
+  launch_wn_units(d_lens, B, T, d_us, d_us + B + 1, 0);
   WnLayerArgs a{};
-  a.h_in = d_h; a.h_out = d_ho; a.skip = d_skip; a.lens = d_lens; a.ustart = d_us; a.wg = d_wg; a.bg = d_bg; a.wr = d_wr; a.br = d_br;
+  a.h_in = d_h; a.h_out = d_ho; a.skip = d_skip; a.lens = d_lens; a.ustart = d_us; a.hmap = d_us + B + 1; a.wg = d_wg; a.bg = d_bg; a.wr = d_wr; a.br = d_br;
   a.B = B; a.H = H; a.T = T; a.Mg_pad = Mg_pad; a.Mr = Mr; a.Mr_pad = Mr_pad; a.last = last; a.skip_accum = 1;
   launch_wn_layer(a, 0);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
