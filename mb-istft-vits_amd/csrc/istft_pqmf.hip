@@ -249,9 +249,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
           polar<FAST, PRE>(xin[k], xin[9 + k], mag, ph, re[k], im[k], k != 0 && k != 8);
           if (own) {
             const int so = ((b * 4 + band) * 9 * F + f) * 4;
-            // write-once streams larger than the Infinity Cache: non-temporal, so that x_post (just
-            // written by subband_conv_post) is not pushed out of the cache ahead of its reads
-            if (a.nt_stores) {
+            if (a.nt_stores) {                         // (experiment, off by default: see the launcher)
               if (a.spec) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, mag), srsrc, so, k * F * 4, 2);
               if (a.phase) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ph), prsrc, so, k * F * 4, 2);
             } else {
@@ -412,7 +410,11 @@ static void launch_istft_pqmf_t(const IstftArgs& a, hipStream_t s) {
 
 void launch_istft_pqmf(const IstftArgs& a_in, hipStream_t s) {
   IstftArgs a = a_in;
-  static const int nt = [] { const char* e = getenv("MBV_ISTFT_NT"); return e ? atoi(e) : 1; }();
+  // Measured and rejected (r02): (a) non-temporal stores for spec / phase / o_mb — 91 vs 84 us for the
+  // all-outputs launch (MBV_ISTFT_NT=1 keeps the A/B); (b) a persistent grid with the next tile's 18
+  // inputs prefetched into registers: needs 80 registers per lane = 3 instead of 4 workgroups per CU,
+  // and loses more to the lower occupancy than the prefetch gains (35.9 / 39.3 vs 32.2 us).
+  static const int nt = [] { const char* e = getenv("MBV_ISTFT_NT"); return e ? atoi(e) : 0; }();
   a.nt_stores = nt;
   // 480 sub-band samples x 512 threads (4 workgroups / CU) by default; MBV_ISTFT_TILE=224 selects
   // the 224 x 256-thread shape (8 workgroups / CU) for A/B runs
