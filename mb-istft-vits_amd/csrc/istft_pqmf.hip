@@ -413,7 +413,13 @@ void launch_istft_pqmf(const IstftArgs& a_in, hipStream_t s) {
   // Measured and rejected (r02): (a) non-temporal stores for spec / phase / o_mb — 91 vs 84 us for the
   // all-outputs launch (MBV_ISTFT_NT=1 keeps the A/B); (b) a persistent grid with the next tile's 18
   // inputs prefetched into registers: needs 80 registers per lane = 3 instead of 4 workgroups per CU,
-  // and loses more to the lower occupancy than the prefetch gains (35.9 / 39.3 vs 32.2 us).
+  // and loses more to the lower occupancy than the prefetch gains (35.9 / 39.3 vs 32.2 us);
+  // (c) 16-byte accesses through in-register 4 x 4 transposes across lane quads (DPP): x_post loads
+  // 36.6 vs 31.6 us, spec / phase stores 84.8 vs 80.0 us in the same run (an apparent 84 -> 75 us gain
+  // was box-to-box variation).  All three are in the history of this file (r02).  What the launch is
+  // bound by: bytes in flight per CU at full occupancy (4 x 512 threads, 18 loads per lane) against
+  // the latency of the level that serves them — 0.81 of the HBM peak from the Infinity Cache, 0.63
+  // from HBM itself (bench.py roofline.past_cache), 0.61-0.65 with all outputs written.
   static const int nt = [] { const char* e = getenv("MBV_ISTFT_NT"); return e ? atoi(e) : 0; }();
   a.nt_stores = nt;
   // 480 sub-band samples x 512 threads (4 workgroups / CU) by default; MBV_ISTFT_TILE=224 selects

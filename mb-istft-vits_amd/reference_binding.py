@@ -1,53 +1,3 @@
-# INTEGRATION — using the MI355X path from the reference code base
-
-The reference (`OER-9000/MB-iSTFT-VITS`) is a flat Python repo; its callers build the model with
-`models.SynthesizerTrn(...)`, load a checkpoint with `utils.load_checkpoint`, and call
-`net.infer(...)` / `net.dec(...)`.  There are two ways to switch them to this build.
-
-## A. Drop-in import (no change to the callers' logic)
-
-```python
-# tts_vits.py:14-16 / synthesis_module.py:9-11  — before
-import utils
-from models import SynthesizerTrn
-# after
-from mb_istft_vits_amd import utils
-from mb_istft_vits_amd.models import SynthesizerTrn
-```
-
-Everything the callers touch keeps its meaning:
-
-| reference use (file:line) | this build |
-|---|---|
-| `utils.get_hparams_from_file(cfg)` → `hps.data.…`, `**hps.model` (`tts_vits.py:70-82`) | `mb_istft_vits_amd.utils.get_hparams_from_file` / `HParams` |
-| `SynthesizerTrn(len(symbols), hps.data.filter_length//2+1, hps.train.segment_size//hps.data.hop_length, n_speakers=…, **hps.model)` (`tts_vits.py:77-82`, `synthesis_module.py:106-112`) | same signature (`models.py:573-599`), extra keys swallowed by `**kwargs` |
-| `.to(device)`, `.eval()`, `utils.load_checkpoint(path, net, None)` (`tts_vits.py:83-85`) | `nn.Module` with exactly the reference's state-dict keys |
-| `net.infer(x, x_lengths, sid=…, noise_scale=…, noise_scale_w=…, length_scale=…)[0][0,0]` (`tts_vits.py:134-137`) | same 8-tuple `(o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)` |
-| `net.infer_z_only(...)` (`models.py:742`), `net.dec(z, g=g)` (`synthesis_module.py:160`), `net.emb_g(sid)` (`synthesis_module.py:158`), `net.n_speakers` | same |
-| `net.voice_conversion(y, y_lengths, sid_src, sid_tgt)` (`models.py:790-798`) | same 4-tuple `(o_hat, o_hat_mb, y_mask, (z, z_p, z_hat))` |
-
-All three decoder families (`mb_istft_vits`, `ms_istft_vits`, `istft_vits`) and both ResBlock
-types are supported.  Differences a maintainer should know: the model must live on a ROCm device
-(`.to("cuda")`) — a CPU model raises instead of computing; `net.forward` (training) raises
-`NotImplementedError`; `use_sdp=True` builds the StochasticDurationPredictor and `noise_scale_w`
-has the reference's meaning (the `[B,2,T]` noise is drawn from torch's default CPU generator at the
-same point as `models.py:94`, so a seeded run reproduces the reference's durations); the state dict has every key of a reference
-checkpoint (`enc_q.*` included), so `load_state_dict` works strictly;
-`timings` is filled from HIP events when first read (reading it synchronises).
-
-## B. Keeping the reference's `models.py` and binding the C ABI underneath
-
-For a maintainer who wants to keep `models.SynthesizerTrn` as the class their code imports (its
-constructor, parameters, `state_dict`, `utils.load_checkpoint`) and only move the inference
-computation, this is the complete reference-side binding: plain `ctypes` over
-`include/mbistft_vits.h`, no dependency on `mb_istft_vits_amd.models`.  It ships as
-`mb-istft-vits_amd/reference_binding.py` and `tests/test_gpu_ops.py::test_reference_side_binding_runs_against_golden`
-runs exactly this text against two goldens of the reference (the reference's `models.py` itself
-cannot travel to the GPU box, so the test binds a parameter-only stand-in with the reference's
-constructor attributes and state-dict keys).  `net.dec` is a sub-module attribute in the reference,
-so the decoder entry is exposed as `net.decode(z, g)` (callers: `synthesis_module.py:160`).
-
-```python
 """The reference-side binding of `include/mbistft_vits.h` (INTEGRATION.md §B), complete and runnable.
 
 For a maintainer who keeps the reference's own `models.SynthesizerTrn` (its constructor, its
@@ -237,63 +187,3 @@ def bind(RefSynthesizerTrn):
 
     SynthesizerTrn.__name__ = RefSynthesizerTrn.__name__
     return SynthesizerTrn
-```
-
-`mb-istft-vits_amd/models.py` is the self-contained version of the same thing (error handling,
-lazy timings, `outputs=` opt-in, `.dec` / `.emb_g` sub-modules, voice conversion, streaming entry points),
-without the dependency on the reference's `models.py`.
-
-## C-ABI summary (`include/mbistft_vits.h`)
-
-| entry point | replaces |
-|---|---|
-| `mbv_create / mbv_destroy` | `SynthesizerTrn.__init__` (`models.py:573-655`) |
-| `mbv_load_weight / mbv_finalize_weights / mbv_missing_weights` | `load_state_dict` as used by `utils.load_checkpoint` (`utils.py:22-47`); weight-norm fold (`torch.nn.utils.weight_norm`, sites SURVEY §2a) |
-| `mbv_encode` | `models.py:701-719` (enc_p, emb_g, dp — `DurationPredictor` or, with `use_sdp`, `StochasticDurationPredictor` reverse — exp/ceil/sum) |
-| `mbv_synthesize` | `models.py:720-734` (mask/path/expand, prior, reverse flow, decoder) |
-| `mbv_decode` | `net.dec(z, g)` (`models.py:344-377 / 430-467`) |
-| `mbv_speaker_embedding` | `net.emb_g(sid)` (`models.py:705`) |
-| `mbv_stage_times_ms` | the `timings` dict (`models.py:698-737`) |
-| `mbv_istft_pqmf` | `TorchSTFT.inverse` + `PQMF.synthesis` / MS tail (`stft.py:197-202`, `pqmf.py:105-116`, `models.py:463-465`) |
-| `mbv_voice_conversion` | `SynthesizerTrn.voice_conversion` (`models.py:790-798`) |
-| `mbv_istft_finalize` | `istft_finalize(net_g, full_complex_spec)` of the chunked-decoding notebooks (`inferz_test.ipynb` cell 6) |
-| `mbv_pcm16` | the normalise / clip / int16 lines of the service wrapper (`tts_vits.py:204-217`) |
-| `mbv_set_option` | run-time switches (`splitk`: low-latency split-K, `istft_exact`, `wn_fused`, `xpost_chunk_bytes`); no reference counterpart |
-| `mbv_kernel_times_ms`, `mbv_read_stage`, `mbv_op_conv1d` | measurement / test introspection (no reference counterpart) |
-
-Errors: every call returns non-zero on failure and `mbv_last_error(handle)` gives the message; the
-Python shim raises `MbvError` / `ValueError` (the reference raises Python exceptions too:
-`synthesis_module.py:153,169`).  Threading: a handle is not re-entrant (the reference's callers
-are single-threaded w.r.t. the model: `tts_vits.py:145,181`).
-
-## Chunked decoding and the service wire format
-
-```python
-attn, y_mask, (z, *_), _ = net.infer_z_only(x, x_lengths, sid=sid, noise_scale=0.1)   # models.py:742
-g = net.emb_g(sid).unsqueeze(-1) if net.n_speakers > 0 else None
-_, _, spec, phase = net.dec(z[:, :, i0:i1], g=g)            # per chunk, as inferz_test.ipynb cell 7
-...                                                         # caller cross-fades spec*exp(1j*phase)
-wave = net.istft_finalize(full_complex_spec, None)          # replaces the notebook's istft_finalize()
-pcm = net.to_pcm16(wave, y_lengths)                         # replaces tts_vits.py:204-217 (int16, bit-exact)
-```
-
-## Low-latency (single utterance) setting
-
-`net.set_option("splitk", 1)` (C ABI: `mbv_set_option(h, "splitk", 1)`; or `MBV_CONV_SPLITK=1` in the
-environment when the model is created) turns on split-K for launches that leave most of the chip idle: `ljs_mb` batch 1, 3 s of audio:
-10.3 → 6.5 ms per `infer` call; `net.dec` on a 32-frame z chunk 4.8 → 1.9 ms.  Results stay deterministic and within fp32 rounding of the default
-mode; only the bitwise equality between "alone" and "inside a big batch" is given up.
-
-## Build
-
-`python -c "import __graft_entry__ as g; g.build()"` — runs `mb-istft-vits_amd/csrc/build.sh`
-(`hipcc --offload-arch=gfx950 -O3 -shared`, no cmake, no torch headers) and leaves
-`libmbistft_vits.so` next to the sources.
-
-## Multi-GPU
-
-`python bench.py --gpus N` (it starts the N ranks itself as child processes; under
-`python -m torch.distributed.run --nproc-per-node N … bench.py --gpus N` it uses the launcher's
-environment) or, from user code, `mb_istft_vits_amd.dist.sharded_infer(net, x, x_lengths, sid)` after
-`init_process_group("nccl")`; `dist.broadcast_state_dict` distributes rank 0's checkpoint.  A caller
-that only needs the waveform passes `outputs=("o",)` to `infer` (the sharded entry does by default).

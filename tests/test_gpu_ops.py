@@ -283,3 +283,58 @@ def test_c_abi_positive_path_with_raw_ctypes():
         assert L.mbv_stage_times_ms(h, C.byref(t5)) == 0 and all(v >= 0 for v in t5)
     finally:
         L.mbv_destroy(h)
+
+
+def test_reference_side_binding_runs_against_golden():
+    """INTEGRATION.md §B as code: `reference_binding.bind(RefClass)` puts the C ABI under a class that
+    has the REFERENCE's constructor attributes and state-dict keys (here a parameter-only stand-in
+    built from the key table — the reference's own models.py does not travel to the GPU box) and
+    must reproduce the reference's `mini_b1` / `uudb_b2` goldens."""
+    from torch import nn
+    from helpers import load_fixture, config_for, rms, FIXTURES
+    from mb_istft_vits_amd import synth, spec as mspec
+    from mb_istft_vits_amd.reference_binding import bind
+
+    class RefStandIn(nn.Module):                    # what `from models import SynthesizerTrn` gives: ctor attrs + parameters
+        def __init__(self, cfg, hps_model, n_speakers):
+            super().__init__()
+            self.n_vocab, self.spec_channels = cfg.n_vocab, cfg.spec_channels
+            self.inter_channels, self.hidden_channels = cfg.inter_channels, cfg.hidden_channels
+            self.filter_channels, self.n_heads, self.n_layers = cfg.filter_channels, cfg.n_heads, cfg.n_layers
+            self.kernel_size, self.upsample_initial_channel = cfg.kernel_size, cfg.upsample_initial_channel
+            self.resblock, self.resblock_kernel_sizes = hps_model["resblock"], hps_model["resblock_kernel_sizes"]
+            self.resblock_dilation_sizes = hps_model["resblock_dilation_sizes"]
+            self.n_speakers, self.gin_channels = n_speakers, hps_model.get("gin_channels", 0)
+            self.use_sdp = hps_model.get("use_sdp", False)
+            self.ms_istft_vits = hps_model.get("ms_istft_vits", False)
+            self.mb_istft_vits = hps_model.get("mb_istft_vits", False)
+            for name, shape in mspec.param_shapes(cfg).items():
+                node, parts = self, name.split(".")
+                for part in parts[:-1]:
+                    if part not in node._modules:
+                        node.add_module(part, nn.Module())
+                    node = node._modules[part]
+                t = torch.zeros(*shape)
+                if name == "dec.updown_filter":
+                    node.register_buffer(parts[-1], t)
+                else:
+                    node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+    Bound = bind(RefStandIn)
+    for fx in ("mini_b1", "uudb_b2"):
+        gold = load_fixture(fx)
+        hps, cfg = config_for(FIXTURES[fx], int(gold["n_vocab"]))
+        net = Bound(cfg, dict(hps.model), hps.data.n_speakers)
+        sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})      # strict: every reference key
+        net = net.cuda().eval()
+        sid = torch.from_numpy(gold["sid"]).cuda() if "sid" in gold else None
+        o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings = net.infer(
+            torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda(), sid=sid,
+            noise_scale=0, length_scale=1)
+        assert np.array_equal(attn.sum(2).cpu().numpy(), gold["attn"]), fx
+        assert rms(o.cpu().numpy() - gold["o"]) < 1e-4, fx
+        assert rms(z.cpu().numpy() - gold["z"]) <= 5e-5 * rms(gold["z"]), fx
+        assert set(timings) == {"text_encoder", "duration_predictor", "alignment_and_projection", "flow", "waveform_decoder"}
+        do = net.decode(z[:, :, :20].contiguous(), None if sid is None else torch.from_numpy(sd["emb_g.weight"])[gold["sid"]].cuda())[0]
+        assert do.shape == (z.shape[0], 1, 256 * 20) and torch.isfinite(do).all()
