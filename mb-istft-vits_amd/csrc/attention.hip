@@ -9,8 +9,7 @@
 // One workgroup of NW = 2 waves per (32-query tile, head, utterance); wave w owns key tiles
 // w, w + NW, ...  At T ~ 200 (7 key tiles, 896 workgroups at batch 64) a tile's work is a
 // latency-bound chain and there are fewer workgroups than SIMDs, so the chain is split across
-// waves; the waves meet twice through LDS: the softmax statistics after pass 1, the partial
-// O^T / band weights after pass 2.  (Measured: 1 wave 205 us, 2 waves see profiles/README.md;
+// waves; the waves meet once through LDS at the end: running max / sum, partial O^T / band weights.  (Measured: 1 wave 205 us, 2 waves see profiles/README.md;
 // 4 waves need 2 rounds of workgroups at 213 registers per lane and are slower.)  The score tile is computed
 // TRANSPOSED (S^T = K^T Q, keys on the accumulator rows, queries on the lanes)
 // so that (a) both MFMA operands are read time-contiguous straight from the
@@ -18,9 +17,8 @@
 // registers (one cross-half shuffle at the end), and (c) the probability tile
 // is already the B operand of the P.V product (O^T = V P^T) with no data
 // movement: k-step s of that product takes accumulator register s.
-// Two passes over the key tiles (max/sum, then normalised P.V) keep P exactly
-// the normalised softmax the reference multiplies by; the contraction cost is
-// negligible at T ~ 200.  The relative-key logits are one extra MFMA tile
+// One pass over the key tiles with running softmax statistics (r02; r01 made two passes and computed
+// every score tile twice).  The relative-key logits are one extra MFMA tile
 // (rows = the 9 embeddings), the relative-value term is accumulated as 9 band
 // weights per query and applied to O^T at the end.
 #include "kernels.h"
@@ -34,7 +32,7 @@ __device__ __forceinline__ int acc_row(int reg, int hl) { return (reg & 3) + 8 *
 constexpr int ATT_NW = 2;          // waves per workgroup (key tiles are dealt round-robin)
 
 template <int DT>
-__global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const float* __restrict__ qkv,
                                                            const float* __restrict__ emb_k,
                                                            const float* __restrict__ emb_v,
                                                            const int* __restrict__ lens,
@@ -108,19 +106,21 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
   const int ntiles = (T + 31) / 32;
   const bool q_valid = tq < len;
 
-  // score tile for key tile kt, masked; rows beyond T get -inf (absent keys)
-  auto score_tile = [&](int kt, f32x16& S) {
-    const int tk0 = kt * 32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-    const int tkl = tk0 + l31;
-    // all K fragments of the tile first (one latency round), then the MFMA chain
-    float kf[DMAX / 2];
-    const int koff = tkl < T ? (hl * T + tkl) * 4 : kOob;
+  // K fragments of key tile kt (A operand of S^T = K^T Q): one latency round, requested early
+  float kf[DMAX / 2];
+  auto load_k = [&](int kt) {
+    const int tkl = kt * 32 + l31;
+    const int koff = (kt < ntiles && tkl < T) ? (hl * T + tkl) * 4 : kOob;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
       kf[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krsrc, koff, s * row2, 0))
                          : 0.f;
+  };
+  // score tile for key tile kt from kf, masked; rows beyond T get -inf (absent keys)
+  auto score_tile = [&](int kt, f32x16& S) {
+    const int tk0 = kt * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
       if (s < nsteps) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], S, 0, 0, 0);
@@ -140,51 +140,13 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
     }
   };
 
-  // ---- pass 1: row max and sum ----------------------------------------------
-  float mx = -INFINITY, sum = 0.f;
-  for (int kt = wave; kt < ntiles; kt += NW) {
-    f32x16 S;
-    score_tile(kt, S);
-    float tmax = S[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
-    const float mnew = fmaxf(mx, tmax);
-    if (mnew > -INFINITY) {
-      float part = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part += expf(S[r] - mnew);
-      sum = sum * expf(mx - mnew) + part;     // exp(-inf) = 0 on the first tile
-      mx = mnew;
-    }
-  }
-  {
-    const float mo = __shfl_xor(mx, 32), so = __shfl_xor(sum, 32);
-    const float mall = fmaxf(mx, mo);
-    const float a = mx > -INFINITY ? sum * expf(mx - mall) : 0.f;
-    const float c = mo > -INFINITY ? so * expf(mo - mall) : 0.f;
-    sum = a + c;
-    mx = mall;
-  }
-  // combine the waves' statistics (every wave folds them in the same order -> identical values)
-  stat[wave][0][lane] = mx;
-  stat[wave][1][lane] = sum;
-  __syncthreads();
-  {
-    float mall = stat[0][0][lane];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) mall = fmaxf(mall, stat[w][0][lane]);
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float mw = stat[w][0][lane];
-      tot += mw > -INFINITY ? stat[w][1][lane] * expf(mw - mall) : 0.f;
-    }
-    mx = mall;
-    sum = tot;
-  }
-  const float rsum = 1.f / sum;
-
-  // ---- pass 2: O^T = V P^T, band weights -------------------------------------
+  // ---- ONE pass over this wave's key tiles, running (max, sum) per query ("online" softmax):
+  //   m' = max(m, max_tile S);  P = exp(S - m');  l = l e^(m - m') + sum P;  O = O e^(m - m') + V P^T
+  // and the same rescaling for the band weights; the division by l happens once at the end.  The
+  // two-pass form (statistics first, then normalised P) computed every score tile twice; the results
+  // differ only in rounding (P is normalised after the contraction instead of before).
+  // Memory latency: V of this tile is requested before the score MFMAs, K of the wave's next tile right
+  // after them (kf is dead by then), so both travel under the arithmetic of the current tile.
   f32x16 O[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t)
@@ -193,13 +155,46 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
   float wb[9];
 #pragma unroll
   for (int q = 0; q < 9; ++q) wb[q] = 0.f;
+  float mx = -INFINITY, sum = 0.f;         // sum: this lane half's share (its 16 keys per tile)
 
+  load_k(wave);
   for (int kt = wave; kt < ntiles; kt += NW) {
     const int tk0 = kt * 32;
+    // V[dd][tk0 + l31] of this tile -> registers (consumed after the softmax arithmetic)
+    float vf[DMAX / 2];
+    {
+      const int voff = tk0 + l31 < T ? (hl * T + tk0 + l31) * 4 : kOob;
+#pragma unroll
+      for (int it = 0; it < DMAX / 2; ++it)
+        vf[it] = it < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, voff, it * row2, 0)) : 0.f;
+    }
     f32x16 S;
     score_tile(kt, S);
+    load_k(kt + NW);                       // (past the last tile: nothing is read)
+    // V -> this wave's Vs[dd][.] as soon as the score chain is issued (it had ~3 k cycles to arrive;
+    // parking it in registers through the softmax arithmetic as well costs a second wave per SIMD).
+    // Wave-private: the LDS accesses of one wave are ordered, no workgroup barrier — the waves run
+    // different trip counts.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = expf(S[r] - mx) * rsum;
+    for (int it = 0; it < DMAX / 2; ++it) Vs[(it * 2 + hl) * VS + l31] = vf[it];
+
+    float tmax = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));          // both halves of a query's 32 keys
+    const float mnew = fmaxf(mx, tmax);                // finite: every tile holds at least one key < T
+    const float alpha = expf(mx - mnew);               // exp(-inf) = 0 on the first tile
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S[r] = expf(S[r] - mnew); part += S[r]; }
+    sum = sum * alpha + part;
+    mx = mnew;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wb[q] *= alpha;
     const bool near = (tk0 - tq0) <= 35 && (tq0 - tk0) <= 35;
     if (near) {
 #pragma unroll
@@ -208,15 +203,6 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
 #pragma unroll
         for (int q = 0; q < 9; ++q) wb[q] += (rr == q) ? S[r] : 0.f;
       }
-    }
-    // stage V[dd][tk0..tk0+31] -> this wave's Vs[dd][.]  (wave-private: the LDS accesses of one
-    // wave are ordered, no workgroup barrier — the waves run different trip counts)
-    const int voff = tk0 + l31 < T ? (hl * T + tk0 + l31) * 4 : kOob;
-#pragma unroll
-    for (int it = 0; it < DMAX / 2; ++it) {
-      const int dd = it * 2 + hl;
-      Vs[dd * VS + l31] = it < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, voff, it * row2, 0))
-                                      : 0.f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -229,11 +215,13 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
         O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[s], O[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_wave_barrier();              // the PV reads are done before the next tile's V lands
   }
+  sum += __shfl_xor(sum, 32);
 #pragma unroll
   for (int q = 0; q < 9; ++q) wb[q] += __shfl_xor(wb[q], 32);
 
-  // ---- fold the waves' partial O^T / band weights into wave 0 ------------------
+  // ---- fold the waves' partial (m, l, O^T, band weights) into wave 0 -------------------------
   __syncthreads();                                    // every wave is done with its V tile
   if (wave > 0) {
     float* dst = Vall + ((wave - 1) * PER) * 64 + lane;
@@ -243,18 +231,43 @@ __global__ __launch_bounds__(64 * ATT_NW) void rel_attention_kernel(const float*
       for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = O[t][r];
 #pragma unroll
     for (int q = 0; q < 9; ++q) dst[(DT * 16 + q) * 64] = wb[q];
+    stat[wave][0][lane] = mx;
+    stat[wave][1][lane] = sum;
   }
   __syncthreads();
   if (wave > 0) return;
+  {
+    float mall = mx;
 #pragma unroll
-  for (int w = 1; w < NW; ++w) {
-    const float* src = Vall + ((w - 1) * PER) * 64 + lane;
+    for (int w = 1; w < NW; ++w) mall = fmaxf(mall, stat[w][0][lane]);
+    const float a0 = expf(mx - mall);
+    sum *= a0;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[t][r] += src[(t * 16 + r) * 64];
+      for (int r = 0; r < 16; ++r) O[t][r] *= a0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) wb[q] += src[(DT * 16 + q) * 64];
+    for (int q = 0; q < 9; ++q) wb[q] *= a0;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float mw = stat[w][0][lane];
+      const float aw = mw > -INFINITY ? expf(mw - mall) : 0.f;      // a wave without key tiles: m = -inf, everything 0
+      sum += stat[w][1][lane] * aw;
+      const float* src = Vall + ((w - 1) * PER) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = fmaf(src[(t * 16 + r) * 64], aw, O[t][r]);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) wb[q] = fmaf(src[(DT * 16 + q) * 64], aw, wb[q]);
+    }
+    const float rsum = 1.f / sum;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= rsum;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wb[q] *= rsum;
   }
 
   // ---- relative values + store ------------------------------------------------
