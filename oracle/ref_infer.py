@@ -590,3 +590,14 @@ def to_pcm16(audio, auto_normalize=True):
     if auto_normalize and peak > 0.01:
         audio = (audio / peak) * 0.9
     return (np.clip(audio, -1.0, 1.0) * 32767).astype(np.int16)
+
+
+def frame_pcm16(audio_int16, rate, frame_length=0.02):
+    """Chunk + base64 framing of tts_vits.py:36-38,219-226 (a loop over t as there)."""
+    import base64
+    chunk = round(frame_length * rate)
+    out, t = [], 0
+    while t < len(audio_int16):
+        out.append(base64.b64encode(np.asarray(audio_int16[t:t + chunk], np.int16).tobytes()).decode("utf-8"))
+        t += chunk
+    return out

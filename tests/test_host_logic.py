@@ -213,3 +213,30 @@ def test_bench_self_launch_builds_a_child_command(monkeypatch):
     assert "MBV_BENCH_SHARE_DEVICES" not in calls["env"]
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
     assert bench.self_launch(bench.parse_args(["--gpus", "2"])) == 1
+
+
+def test_wire_framing_matches_the_service_wrapper():
+    """20 ms int16 frames as base64 text (tts_vits.py:36-38, 219-226): against the oracle's loop and
+    against known answers (frame count, last short frame, byte-exact round trip)."""
+    import base64
+    from mb_istft_vits_amd import wire
+    from oracle import ref_infer as R
+    rs = np.random.RandomState(0)
+    pcm = rs.randint(-32768, 32767, size=22050 + 137).astype(np.int16)
+    for rate, fl in ((24000, 0.02), (22050, 0.02), (16000, 0.0125)):
+        got = wire.frame_pcm16(pcm, rate, fl)
+        assert got == R.frame_pcm16(pcm, rate, fl)
+        n = round(fl * rate)
+        assert wire.chunk_size(rate, fl) == n and len(got) == -(-len(pcm) // n)
+        back = np.frombuffer(b"".join(base64.b64decode(s) for s in got), dtype="<i2")
+        assert np.array_equal(back, pcm)
+        assert len(base64.b64decode(got[-1])) == 2 * (len(pcm) - n * (len(got) - 1))
+    assert wire.frame_pcm16(pcm, 24000, valid_samples=1000) == R.frame_pcm16(pcm[:1000], 24000)
+    assert wire.frame_pcm16(np.zeros(0, np.int16), 24000) == []
+    # known answer: 480 samples at 24 kHz = one frame of 960 bytes -> 1280 base64 characters
+    one = wire.frame_pcm16(np.arange(480, dtype=np.int16), 24000)
+    assert len(one) == 1 and len(one[0]) == 1280 and one[0].startswith("AAABAAIAAwAEAAUA")
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        wire.frame_pcm16(pcm.astype(np.float32), 24000)
+    assert wire.frame_pcm16(torch.from_numpy(pcm[:960]), 24000) == R.frame_pcm16(pcm[:960], 24000)
