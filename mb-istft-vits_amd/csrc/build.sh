@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 OBJS=""
 PIDS=""
-for f in conv1d wn_fused ops sdp attention istft_pqmf capi; do
+for f in conv1d conv1d_narrow wn_fused ops sdp attention istft_pqmf capi; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ kernels.h -nt $f.o ] || [ ../../include/mbistft_vits.h -nt $f.o ]; then
     rm -f $f.o                     # a failed compile must not leave a stale object to link
     $HIPCC $FLAGS -c $f.hip -o $f.o &

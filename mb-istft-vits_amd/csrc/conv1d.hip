@@ -785,6 +785,20 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
+  // Few columns (the low-latency mode's single utterances): 32-column units with the rows split over
+  // waves and workgroups (conv1d_narrow.hip) instead of 128-column tiles + split-K.  Only in the
+  // opt-in low-latency mode: like split-K it changes the summation order with the launch size.
+  // MBV_CONV_NARROW: 0 = never, 1 = default rule, 2 = whenever supported (experiments).
+  {
+    static const int narrow = [] { const char* e = getenv("MBV_CONV_NARROW"); return e ? atoi(e) : 1; }();
+    if (narrow && conv1d_narrow_supported(a)) {
+      const long tiles128 = (long)((a.T + 127) / 128) * ((a.M + 127) / 128) * a.B;
+      // (a handful of column tiles — the text encoder of one short utterance — is better served by
+      // split-K over the long Cin loop than by 8 workgroups walking it alone)
+      const long units32 = (((long)a.B * ((a.T + 15) / 16) + 1) / 2) * ((a.M + 127) / 128);
+      if (narrow >= 2 || (a.splitk && tiles128 <= 128 && units32 >= 48)) { launch_conv1d_narrow(a, s); return; }
+    }
+  }
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE || a.epi == EPI_CONVT;
   // Long sequences with enough blocks to fill the chip: 512-thread workgroups, 128 x 384 tile
   // (6 accumulators per wave), double-buffered LDS.  Otherwise 256-thread, 128 x 128 tile.

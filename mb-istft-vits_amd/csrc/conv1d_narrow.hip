@@ -1,0 +1,344 @@
+// conv1d for launches with few columns (single utterances, short sequences): the same contraction as
+// conv1d.hip, decomposed the way wn_fused.hip is.
+//
+// conv1d.hip tiles the output 128 rows x 128 / 384 columns per workgroup; one utterance of 3 s is 34
+// such tiles of a 128-channel decoder conv on a 256-CU chip, and the split-K detour that spreads them
+// (partials through memory, ticket, ordered reduce) costs more than the contraction (74-95 us for
+// ~1 GFLOP).  Here a work unit is 32 COLUMNS x one ROW BLOCK:
+//   * columns: two half-units of 16 consecutive frames, each inside one utterance, numbered through the
+//     batch (hu -> utterance hu / hpu, first frame 16 (hu % hpu)); tile c takes half-units 2c, 2c + 1,
+//     so no column is padded beyond a multiple of 16;
+//   * rows: the 4 waves of a 256-thread workgroup own row tiles wave, wave + 4, ... (NRT each) of a row
+//     block of 128 NRT rows; row blocks of one column tile are separate workgroups (no reduction:
+//     rows are independent), so a 128-channel conv on 4 240 frames is 133 workgroups of 4 x 1 tile;
+//   * the A operand comes straight from L2 (a lane's four K-steps = one 16-byte load of the packed
+//     weights conv1d.hip uses too), through a register ring three steps ahead; the input window (all
+//     channels of a block of CB channels x 2 x (16 + halo) frames, activation / mask / conditioning
+//     applied on the way in) is the only thing staged in LDS; two barriers per channel block.
+// Epilogues: STORE (+ relu, + output mask), RESID, RESID_ACC — what the text encoder and the
+// decoder's ResBlocks need; everything else stays on conv1d.hip.
+#include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace mbv {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHalf = 16;
+constexpr int kRsrcFlags = 0x00020000;
+constexpr unsigned kOob = 0x7fffffffu;
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float lrelu_(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+struct NarrowGeom {
+  int hpu;        // half-units per utterance: ceil(T / 16)
+  int n_ctiles;   // column tiles: ceil(B hpu / 2)
+  int n_rblk;     // row blocks of 128 NRT rows
+  int CB;         // channels per staged block (multiple of 8, divides Cin)
+  int XS;         // column stride of a half-unit's window in the LDS image (multiple of 16, >= 16 + halo)
+};
+
+template <int NRT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a, const NarrowGeom gm) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);                     // [CB / 8][2][2 XS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int half = l31 >> 4, jl = l31 & 15;
+  const int K = a.K, T = a.T, M = a.M;
+  const int G = a.Cin / 8, GB = gm.CB / 8, XL = 2 * gm.XS;
+  const int W = kHalf + (K - 1) * a.dil;                               // window of a half-unit
+  const int nblk = a.Cin / gm.CB;
+  const int steps_blk = GB * K;
+  const int n_hu = a.B * gm.hpu;
+
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.Cin * a.Mpad * 4, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? M * 4 : 0, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)(a.B * a.x_bstride) * 4u, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (unsigned)(a.B * a.y_bstride) * 4u, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t r_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.res ? (unsigned)(a.B * a.res_bstride) * 4u : 0u, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t ac_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.accum_in), 0, a.accum_in ? (unsigned)(a.B * a.y_bstride) * 4u : 0u, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t rc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res_chan_add), 0, a.res_chan_add ? a.B * M * 4 : 0, kRsrcFlags);
+  const unsigned w_step = (unsigned)(2 * a.Mpad * 16);                 // bytes per (tap, group) step
+  const unsigned rowT = (unsigned)T * 4u;
+
+  // A ring: kD slots, loads run kD - 1 steps ahead.  A step is 4 NRT MFMAs (256 NRT cycles), the ring has
+  // to cover an L2 round trip (~1-2 k cycles under load): deep for one row tile per wave, shallow for six.
+  constexpr int kD = NRT == 1 ? 12 : (NRT == 2 ? 8 : 4);
+  const int n_units = gm.n_ctiles * gm.n_rblk;
+  for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int ct = u / gm.n_rblk, rb = u - ct * gm.n_rblk;
+    // the two half-units: utterance, first frame, "exists"
+    int hb[2], ht0[2], hok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int hu = 2 * ct + k;
+      hok[k] = hu < n_hu;
+      const int huc = hok[k] ? hu : n_hu - 1;
+      hb[k] = huc / gm.hpu;
+      ht0[k] = (huc - hb[k] * gm.hpu) * kHalf;
+    }
+    const int b = half ? hb[1] : hb[0];
+    const int t = (half ? ht0[1] : ht0[0]) + jl;                       // this lane's output frame
+    const bool tv = (half ? hok[1] : hok[0]) && t < T;
+    const int row_blk0 = rb * (128 * NRT);
+    const unsigned w_voff = (unsigned)((hl * a.Mpad + row_blk0 + wave * 32 + l31) * 16);
+    const unsigned y_voff = tv ? (unsigned)(b * (int)a.y_bstride + 4 * hl * T + t) * 4u : kOob;
+    const int xoff = half * gm.XS + jl;
+
+    // ---- accumulators start from bias (+ what the epilogue would have to read) -----------------
+    f32x16 acc[NRT];
+    {
+      const unsigned bvo = (unsigned)(4 * hl) * 4u;
+      const unsigned r_voff = tv ? (unsigned)(b * (int)a.res_bstride + 4 * hl * T + t) * 4u : kOob;
+      const unsigned rc_voff = (unsigned)(b * M + 4 * hl) * 4u;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = bload4(b_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);  // past M / no bias: reads 0
+          if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) {
+            if (a.res_chan_add && row0 < M) v += bload4(rc_rs, rc_voff, (unsigned)(row0 + 8 * q) * 4u);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            float x = v[s];
+            if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) {
+              if (row0 < M) {
+                x += bload1(r_rs, r_voff, (unsigned)(row0 + 8 * q + s) * rowT);
+                if (EPI == EPI_RESID_ACC && a.accum_in) x += bload1(ac_rs, y_voff, (unsigned)(row0 + 8 * q + s) * rowT);
+              }
+            }
+            acc[j][4 * q + s] = x;
+          }
+        }
+      }
+    }
+
+    constexpr bool kTwoAcc = NRT <= 2;
+    f32x16 acc2[kTwoAcc ? NRT : 1];
+    if constexpr (kTwoAcc) {
+#pragma unroll
+      for (int j = 0; j < NRT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+    }
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int g0 = blk * GB;
+      // ---- A ring: the first kD - 1 steps of this block (step = g * K + tap inside the block) ----
+      f32x4 ra[kD][NRT];
+      {
+        int tap = 0, gl = 0;
+#pragma unroll
+        for (int d = 0; d < kD - 1; ++d) {
+          const unsigned so = (unsigned)(tap * G + g0 + gl) * w_step;
+#pragma unroll
+          for (int j = 0; j < NRT; ++j) ra[d][j] = bload4(w_rs, w_voff, so + j * 2048u);
+          if (++tap == K) { tap = 0; ++gl; }
+          if (gl >= GB) { gl = GB - 1; tap = K - 1; }                 // fewer steps than slots: harmless re-load
+        }
+      }
+      __syncthreads();                                                 // the previous block's / unit's readers of Xs are done
+      // ---- input window of this channel block: [GB][2][2 XS], activated, masked.  The loads of NXI
+      // items per thread are all issued before the first is used (one memory latency per batch
+      // instead of one per item: at batch 1 a workgroup has nothing else to hide them behind).
+      {
+        constexpr int NXI = NRT <= 2 ? 16 : (NRT <= 4 ? 8 : 4);
+        const int items = GB * 2 * XL;
+        const unsigned rs2 = 2u * (unsigned)a.x_rstride * 4u;
+        for (int e0 = 0; e0 < items; e0 += 256 * NXI) {
+          f32x4 xw[NXI];
+          int chs[NXI];
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) {
+            const int e = e0 + tid + 256 * i;
+            const int P = e / XL, cc = e - P * XL;
+            const int k = cc >= gm.XS, c2 = cc - k * gm.XS;
+            const int bb = k ? hb[1] : hb[0];
+            const int ti = (k ? ht0[1] : ht0[0]) - a.pad_left + c2;
+            const int lim = a.in_lens ? min(a.in_lens[bb], a.Tin) : a.Tin;
+            const int ch = (g0 + (P >> 1)) * 8 + (P & 1);
+            const bool ok = e < items && c2 < W && (k ? hok[1] : hok[0]) && ti >= 0 && ti < lim;
+            const unsigned vo = ok ? (unsigned)(bb * (int)a.x_bstride + ch * a.x_rstride + ti) * 4u : kOob;
+            xw[i][0] = bload1(x_rs, vo, 0); xw[i][1] = bload1(x_rs, vo, rs2);
+            xw[i][2] = bload1(x_rs, vo, 2 * rs2); xw[i][3] = bload1(x_rs, vo, 3 * rs2);
+            chs[i] = ok ? bb * a.Cin + ch : -1;
+          }
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) {
+            const int e = e0 + tid + 256 * i;
+            if (e < items) {
+              f32x4 v = xw[i];
+              if (chs[i] >= 0) {
+                if (a.chan_add) {
+                  const float* ca = a.chan_add + chs[i];
+                  v[0] += ca[0]; v[1] += ca[2]; v[2] += ca[4]; v[3] += ca[6];
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu_(v[s4], a.in_slope);
+              }
+              Xs[e] = v;
+            }
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- MFMA over the block's (group, tap) steps ----------------------------------------------
+      {
+        const f32x4* xl = Xs + hl * XL + xoff;
+        int tap = 0, gl = 0;              // step being multiplied
+        int ltap = 0, lgl = 0;            // step whose A operands are loaded next (kD - 1 ahead)
+#pragma unroll
+        for (int d = 0; d < kD - 1; ++d) { if (++ltap == K) { ltap = 0; ++lgl; } }
+        f32x4 bv = xl[0];
+        for (int s0 = 0; s0 < steps_blk; s0 += kD) {
+#pragma unroll
+          for (int d = 0; d < kD; ++d) {
+            if (s0 + d < steps_blk) {
+              {
+                const int lg = lgl < GB ? lgl : GB - 1;               // past the block: re-load its last step (unused)
+                const unsigned so = (unsigned)((lgl < GB ? ltap : K - 1) * G + g0 + lg) * w_step;
+#pragma unroll
+                for (int j = 0; j < NRT; ++j) ra[(d + kD - 1) % kD][j] = bload4(w_rs, w_voff, so + j * 2048u);
+                if (++ltap == K) { ltap = 0; ++lgl; }
+              }
+              int ntap = tap + 1, ngl = gl;
+              if (ntap == K) { ntap = 0; ++ngl; }
+              if (ngl >= GB) { ngl = gl; ntap = tap; }
+              const f32x4 bn = xl[ngl * 2 * XL + ntap * a.dil];
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (kTwoAcc) {
+                // one row tile per wave is ONE dependent MFMA chain, which does not issue back to back:
+                // the K-steps alternate between two accumulator sets (summed before the stores)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                  for (int j = 0; j < NRT; ++j) {
+                    if (s4 & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc2[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc[j], 0, 0, 0);
+                  }
+              } else {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                  for (int j = 0; j < NRT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc[j], 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              bv = bn;
+              tap = ntap; gl = ngl;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- stores (masked lanes' stores are dropped by the range check) ------------------------------
+    {
+      const bool keep = !a.out_lens || t < a.out_lens[b];
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        if (row0 >= M) continue;                                       // idle tile slot (rows past M would land in the next utterance)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = (r & 3) + 8 * (r >> 2);
+          float v = acc[j][r];
+          if constexpr (kTwoAcc) v += acc2[j][r];
+          if constexpr (EPI == EPI_STORE) {
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (!keep) v = 0.f;
+          } else if constexpr (EPI == EPI_RESID_ACC) {
+            v *= a.out_scale;
+          }
+          if (row0 + k + 4 * hl < M) bstore1(v, y_rs, y_voff, (unsigned)(row0 + k) * rowT);
+        }
+      }
+    }
+  }
+}
+
+template <int NRT, int EPI>
+void launch_narrow_t(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
+  const size_t lds_bytes = (size_t)(gm.CB / 8) * 2 * 2 * gm.XS * 16;
+  const long units = (long)gm.n_ctiles * gm.n_rblk;
+  const int grid = (int)(units < 512 ? (units < 1 ? 1 : units) : 512);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_narrow_kernel<NRT, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv1d_narrow_kernel<NRT, EPI>), dim3(grid), dim3(256), lds_bytes, s, a, gm);
+}
+
+template <int NRT>
+void launch_narrow_epi(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
+  switch (a.epi) {
+    case EPI_STORE: launch_narrow_t<NRT, EPI_STORE>(a, gm, s); break;
+    case EPI_RESID: launch_narrow_t<NRT, EPI_RESID>(a, gm, s); break;
+    default: launch_narrow_t<NRT, EPI_RESID_ACC>(a, gm, s); break;
+  }
+}
+
+}  // namespace
+
+// What the narrow kernel covers: the three plain epilogues, rows in whole 32-row tiles, no reflect
+// padding, tensors addressable with 32-bit byte offsets.
+bool conv1d_narrow_supported(const ConvArgs& a) {
+  if (a.epi != EPI_STORE && a.epi != EPI_RESID && a.epi != EPI_RESID_ACC) return false;
+  if (a.reflect1 || a.M % 32 || a.Cin % 8 || a.K < 1 || a.K > 11) return false;
+  if (a.x_rstride != a.Tin && a.x_rstride < a.Tin) return false;
+  const unsigned long long lim = 1ull << 31;
+  if ((unsigned long long)a.B * a.x_bstride * 4 >= lim || (unsigned long long)a.B * a.y_bstride * 4 >= lim) return false;
+  if (a.res && (unsigned long long)a.B * a.res_bstride * 4 >= lim) return false;
+  const int W = kHalf + (a.K - 1) * a.dil;
+  return W <= 96;
+}
+
+void launch_conv1d_narrow(const ConvArgs& a, hipStream_t s) {
+  NarrowGeom gm;
+  gm.hpu = (a.T + kHalf - 1) / kHalf;
+  gm.n_ctiles = (int)(((long)a.B * gm.hpu + 1) / 2);
+  const int W = kHalf + (a.K - 1) * a.dil;
+  gm.XS = (W + 15) / 16 * 16;
+  // channel block: the largest divisor of Cin (in groups of 8) whose window image fits 64 KB (two
+  // workgroups per CU) — or 128 KB when there is at most one workgroup per CU anyway
+  const size_t lds_cap = (long)gm.n_ctiles * ((a.M + 127) / 128) <= 256 ? 128 * 1024 : 64 * 1024;
+  int cb = a.Cin;
+  while (cb > 8 && ((size_t)cb * gm.XS * 8 > lds_cap || a.Cin % cb)) cb -= 8;
+  gm.CB = cb;
+  // row tiles per wave: few columns -> small row blocks (more workgroups); many columns -> the whole
+  // height in one workgroup (the window is staged once per row block)
+  const int tiles_m = (a.M + 31) / 32;
+  int nrt = (tiles_m + 3) / 4;
+  if (nrt > 6) nrt = 6;
+  while (nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
+  if (nrt == 5) nrt = 6;
+  gm.n_rblk = (tiles_m + 4 * nrt - 1) / (4 * nrt);
+  switch (nrt) {
+    case 1: launch_narrow_epi<1>(a, gm, s); break;
+    case 2: launch_narrow_epi<2>(a, gm, s); break;
+    case 3: launch_narrow_epi<3>(a, gm, s); break;
+    case 4: launch_narrow_epi<4>(a, gm, s); break;
+    default: launch_narrow_epi<6>(a, gm, s); break;
+  }
+}
+
+}  // namespace mbv

@@ -352,7 +352,7 @@ def test_oversized_batch_is_split_not_refused():
         split = net.dec(z)
         net.set_option("xpost_chunk_bytes", 0)
         for a, b in zip(whole, split):
-            assert (a is None and b is None) or torch.equal(a, b), cfg_name
+            assert (a is None and b is None) or _same_rows(b, a), cfg_name     # bitwise (within rounding in split-K mode)
     net, sd = make_net("ljs_mini_istft_vits")
     B, Tp = 540, 870
     assert B * 18 * (64 * Tp + 1) * 4 >= 2 ** 31
