@@ -785,10 +785,14 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
-  // Few columns (the low-latency mode's single utterances): 32-column units with the rows split over
-  // waves and workgroups (conv1d_narrow.hip) instead of 128-column tiles + split-K.  Only in the
-  // opt-in low-latency mode: like split-K it changes the summation order with the launch size.
-  // MBV_CONV_NARROW: 0 = never, 1 = default rule, 2 = whenever supported (experiments).
+  // conv1d_narrow.hip (32-column units, rows split over waves, weights from L2) takes over where the
+  // 128-column tiles below fit badly:
+  //   (a) every sequence of <= 256 frames (the text encoder, the duration predictor): T = 200 fills
+  //       1.56 tiles of 128 columns; a rule on T alone, so a row's arithmetic never depends on the batch;
+  //   (b) in the opt-in low-latency mode, launches that would leave most of the chip idle (single
+  //       utterances) instead of 128-column tiles + split-K: like split-K this makes the summation
+  //       order a function of the launch size.
+  // MBV_CONV_NARROW: 0 = never, 1 = these rules, 2 = whenever supported (experiments).
   {
     static const int narrow = [] { const char* e = getenv("MBV_CONV_NARROW"); return e ? atoi(e) : 1; }();
     if (narrow && conv1d_narrow_supported(a)) {
@@ -796,7 +800,12 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
       // (a handful of column tiles — the text encoder of one short utterance — is better served by
       // split-K over the long Cin loop than by 8 workgroups walking it alone)
       const long units32 = (((long)a.B * ((a.T + 15) / 16) + 1) / 2) * ((a.M + 127) / 128);
-      if (narrow >= 2 || (a.splitk && tiles128 <= 128 && units32 >= 48)) { launch_conv1d_narrow(a, s); return; }
+      if (a.splitk && tiles128 <= 128) {
+        if (units32 >= 48 || narrow == 2) { launch_conv1d_narrow(a, true, s); return; }
+      } else if (a.T <= 256 || narrow == 2) {
+        launch_conv1d_narrow(a, false, s);
+        return;
+      }
     }
   }
   const bool wide_m = a.M > 64 || a.epi == EPI_GATE || a.epi == EPI_CONVT;

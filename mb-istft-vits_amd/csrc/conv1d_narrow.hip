@@ -312,7 +312,10 @@ bool conv1d_narrow_supported(const ConvArgs& a) {
   return W <= 96;
 }
 
-void launch_conv1d_narrow(const ConvArgs& a, hipStream_t s) {
+// by_launch_size: pick the row-block height from the number of column tiles (the low-latency mode: more,
+// smaller workgroups for single utterances).  false: from M alone, so that the summation order of a
+// row never depends on what else is in the batch (the default mode's bitwise batch independence).
+void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s) {
   NarrowGeom gm;
   gm.hpu = (a.T + kHalf - 1) / kHalf;
   gm.n_ctiles = (int)(((long)a.B * gm.hpu + 1) / 2);
@@ -320,7 +323,7 @@ void launch_conv1d_narrow(const ConvArgs& a, hipStream_t s) {
   gm.XS = (W + 15) / 16 * 16;
   // channel block: the largest divisor of Cin (in groups of 8) whose window image fits 64 KB (two
   // workgroups per CU) — or 128 KB when there is at most one workgroup per CU anyway
-  const size_t lds_cap = (long)gm.n_ctiles * ((a.M + 127) / 128) <= 256 ? 128 * 1024 : 64 * 1024;
+  const size_t lds_cap = (by_launch_size && (long)gm.n_ctiles * ((a.M + 127) / 128) <= 256) ? 128 * 1024 : 64 * 1024;
   int cb = a.Cin;
   while (cb > 8 && ((size_t)cb * gm.XS * 8 > lds_cap || a.Cin % cb)) cb -= 8;
   gm.CB = cb;
@@ -329,7 +332,7 @@ void launch_conv1d_narrow(const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + 31) / 32;
   int nrt = (tiles_m + 3) / 4;
   if (nrt > 6) nrt = 6;
-  while (nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
+  while (by_launch_size && nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
   if (nrt == 5) nrt = 6;
   gm.n_rblk = (tiles_m + 4 * nrt - 1) / (4 * nrt);
   switch (nrt) {

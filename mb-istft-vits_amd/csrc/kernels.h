@@ -75,7 +75,7 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
 // conv1d_narrow.hip: the same contraction in 32-column x row-block units (launches with few columns)
 bool conv1d_narrow_supported(const ConvArgs& a);
-void launch_conv1d_narrow(const ConvArgs& a, hipStream_t s);
+void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s);
 
 // ---------------------------------------------------------------- fused WN layer (wn_fused.hip)
 // One layer of modules.WN (k = 5, dilation 1) in one launch: gate conv + tanh*sigmoid + 1x1 res/skip +
