@@ -15,6 +15,9 @@
 //     weights conv1d.hip uses too), through a register ring three steps ahead; the input window (all
 //     channels of a block of CB channels x 2 x (16 + halo) frames, activation / mask / conditioning
 //     applied on the way in) is the only thing staged in LDS; two barriers per channel block.
+// (Measured and dropped, r02: two column tiles per workgroup with the rows over two waves each, for
+// heights of 6 row tiles that four waves split 2 / 2 / 1 / 1 — the better balance is paid for with half
+// as many workgroups: text encoder 3.03 -> 2.99 ms at batch 64 but 2.15 -> 2.53 ms at batch 32.)
 // Epilogues: STORE (+ relu, + output mask), RESID, RESID_ACC — what the text encoder and the
 // decoder's ResBlocks need; everything else stays on conv1d.hip.
 #include "kernels.h"
@@ -333,13 +336,13 @@ void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s)
   int nrt = (tiles_m + 3) / 4;
   if (nrt > 6) nrt = 6;
   while (by_launch_size && nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
-  if (nrt == 5) nrt = 6;
   gm.n_rblk = (tiles_m + 4 * nrt - 1) / (4 * nrt);
   switch (nrt) {
     case 1: launch_narrow_epi<1>(a, gm, s); break;
     case 2: launch_narrow_epi<2>(a, gm, s); break;
     case 3: launch_narrow_epi<3>(a, gm, s); break;
     case 4: launch_narrow_epi<4>(a, gm, s); break;
+    case 5: launch_narrow_epi<5>(a, gm, s); break;
     default: launch_narrow_epi<6>(a, gm, s); break;
   }
 }
