@@ -1242,26 +1242,47 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   HIPCHK(m, hipEventRecord(m->ev[0], s));
   launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, bad, B, T, H, c.n_vocab, s);
   const int64_t bsH = (int64_t)H * T;
+  static const int fuse_ln_env = [] { const char* e = getenv("MBV_FUSE_LN"); return e ? atoi(e) : 1; }();
+  const bool fuse_ln = fuse_ln_env && T <= 256;        // (a rule on T alone: rows stay batch-independent)
   for (int i = 0; i < c.n_layers; ++i) {
     const auto& L = m->enc[i];
     launch_conv1d(conv_args(m, L.qkv, x, bsH, T, qkv, 3 * bsH, T, B), s);
     launch_rel_attention(qkv, m->W(L.ek.off), m->W(L.ev.off), m->lens32, att, B, H, c.n_heads, T, s);
-    launch_conv1d(conv_args(m, L.o, att, bsH, T, y, bsH, T, B), s);
-    launch_layernorm(x, y, m->W(L.g1.off), m->W(L.b1.off), x1, B, H, T, 0, nullptr, s);
+    // conv_o and the LayerNorm(x + y) behind it (attentions.py:40-41): one launch on the narrow kernel
+    // for sequences it covers (a rule on T and H only), else conv + LayerNorm
+    {
+      ConvArgs a = conv_args(m, L.o, att, bsH, T, x1, bsH, T, B);
+      a.epi = EPI_LN; a.res = x; a.res_bstride = bsH;
+      a.ln_gamma = m->W(L.g1.off); a.ln_beta = m->W(L.b1.off);
+      if (fuse_ln && conv1d_narrow_supported(a)) {
+        launch_conv1d(a, s);
+      } else {
+        launch_conv1d(conv_args(m, L.o, att, bsH, T, y, bsH, T, B), s);
+        launch_layernorm(x, y, m->W(L.g1.off), m->W(L.b1.off), x1, B, H, T, 0, nullptr, s);
+      }
+    }
     {
       ConvArgs a = conv_args(m, L.ffn1, x1, bsH, T, ffn, (int64_t)Fc * T, T, B);
       a.pad_left = (c.kernel_size - 1) / 2;            // attentions.py:296-303
       a.in_lens = m->lens32; a.relu = 1;
       launch_conv1d(a, s);
     }
-    {
-      ConvArgs a = conv_args(m, L.ffn2, ffn, (int64_t)Fc * T, T, y, bsH, T, B);
+    const bool last = i == c.n_layers - 1;
+    {   // FFN's second conv (output masked, attentions.py:303) and LayerNorm(x1 + y) (+ the final mask, :45-46)
+      ConvArgs a = conv_args(m, L.ffn2, ffn, (int64_t)Fc * T, T, x, bsH, T, B);
       a.pad_left = (c.kernel_size - 1) / 2;
       a.in_lens = m->lens32; a.out_lens = m->lens32;
-      launch_conv1d(a, s);
+      a.epi = EPI_LN; a.res = x1; a.res_bstride = bsH;
+      a.ln_gamma = m->W(L.g2.off); a.ln_beta = m->W(L.b2.off);
+      a.ln_out_lens = last ? m->lens32 : nullptr;
+      if (fuse_ln && conv1d_narrow_supported(a)) {
+        launch_conv1d(a, s);
+      } else {
+        a.epi = EPI_STORE; a.res = nullptr; a.y = y; a.ln_gamma = a.ln_beta = nullptr; a.ln_out_lens = nullptr;
+        launch_conv1d(a, s);
+        launch_layernorm(x1, y, m->W(L.g2.off), m->W(L.b2.off), x, B, H, T, 0, last ? m->lens32 : nullptr, s);
+      }
     }
-    const bool last = i == c.n_layers - 1;
-    launch_layernorm(x1, y, m->W(L.g2.off), m->W(L.b2.off), x, B, H, T, 0, last ? m->lens32 : nullptr, s);
   }
   m->x_enc = x;
   {
@@ -1315,19 +1336,34 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
     m->stages["sdp_cond"] = {cond, (int64_t)BT * H};
     m->stages["sdp_z"] = {zf, (int64_t)BT * 2};
   } else {
+  // conv -> relu -> LayerNorm twice (models.py:128-135): each pair one launch where the narrow kernel applies
+  const float* dp_out = h2;
   {
-    ConvArgs a = conv_args(m, m->dp1, x, bsH, T, h1, (int64_t)kDpFilter * T, T, B);
+    ConvArgs a = conv_args(m, m->dp1, x, bsH, T, h2, (int64_t)kDpFilter * T, T, B);
     a.in_lens = m->lens32; a.chan_add = cadd;
-    launch_conv1d(a, s);
+    a.epi = EPI_LN; a.relu = 1; a.ln_gamma = m->W(m->dp_g1.off); a.ln_beta = m->W(m->dp_b1.off);
+    if (fuse_ln && conv1d_narrow_supported(a)) {
+      launch_conv1d(a, s);
+    } else {
+      a.epi = EPI_STORE; a.relu = 0; a.y = h1; a.ln_gamma = a.ln_beta = nullptr;
+      launch_conv1d(a, s);
+      launch_layernorm(h1, nullptr, m->W(m->dp_g1.off), m->W(m->dp_b1.off), h2, B, kDpFilter, T, 1, nullptr, s);
+    }
   }
-  launch_layernorm(h1, nullptr, m->W(m->dp_g1.off), m->W(m->dp_b1.off), h2, B, kDpFilter, T, 1, nullptr, s);
   {
     ConvArgs a = conv_args(m, m->dp2, h2, (int64_t)kDpFilter * T, T, h1, (int64_t)kDpFilter * T, T, B);
     a.in_lens = m->lens32;
-    launch_conv1d(a, s);
+    a.epi = EPI_LN; a.relu = 1; a.ln_gamma = m->W(m->dp_g2.off); a.ln_beta = m->W(m->dp_b2.off);
+    if (fuse_ln && conv1d_narrow_supported(a)) {
+      launch_conv1d(a, s);
+      dp_out = h1;
+    } else {
+      a.epi = EPI_STORE; a.relu = 0; a.ln_gamma = a.ln_beta = nullptr;
+      launch_conv1d(a, s);
+      launch_layernorm(h1, nullptr, m->W(m->dp_g2.off), m->W(m->dp_b2.off), h2, B, kDpFilter, T, 1, nullptr, s);
+    }
   }
-  launch_layernorm(h1, nullptr, m->W(m->dp_g2.off), m->W(m->dp_b2.off), h2, B, kDpFilter, T, 1, nullptr, s);
-  launch_durations(h2, m->W(m->dp_pw.off), m->W(m->dp_pb.off), m->lens32, length_scale, m->logw,
+  launch_durations(dp_out, m->W(m->dp_pw.off), m->W(m->dp_pb.off), m->lens32, length_scale, m->logw,
                    m->w_ceil, m->cum, m->ylen32, y_lengths_out, bad, B, kDpFilter, T, s);
   }
   HIPCHK(m, hipEventRecord(m->ev[2], s));

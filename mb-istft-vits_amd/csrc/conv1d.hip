@@ -795,6 +795,11 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   // MBV_CONV_NARROW: 0 = never, 1 = these rules, 2 = whenever supported (experiments).
   {
     static const int narrow = [] { const char* e = getenv("MBV_CONV_NARROW"); return e ? atoi(e) : 1; }();
+    if (a.epi == EPI_LN) {
+      if (!conv1d_narrow_supported(a)) { fprintf(stderr, "mbv: EPI_LN outside the narrow kernel's range\n"); abort(); }
+      launch_conv1d_narrow(a, false, s);
+      return;
+    }
     if (narrow && conv1d_narrow_supported(a)) {
       const long tiles128 = (long)((a.T + 127) / 128) * ((a.M + 127) / 128) * a.B;
       // (a handful of column tiles — the text encoder of one short utterance — is better served by

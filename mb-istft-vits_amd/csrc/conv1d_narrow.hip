@@ -252,6 +252,66 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       }
     }
 
+    if constexpr (EPI == EPI_LN) {
+      // ---- conv -> (relu) -> (mask) -> + residual -> channel LayerNorm -> affine -> (mask): the workgroup
+      // holds every channel of its 32 frames (one row block), the statistics of a frame are reduced over
+      // the lane's registers, its two lane halves and the four waves (LDS); two passes like F.layer_norm.
+      const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ln_gamma), 0, M * 4, kRsrcFlags);
+      const __amdgpu_buffer_rsrc_t be_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ln_beta), 0, M * 4, kRsrcFlags);
+      const unsigned r_voff = tv ? (unsigned)(b * (int)a.res_bstride + 4 * hl * T + t) * 4u : kOob;
+      const bool keep = !a.out_lens || t < a.out_lens[b];
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = (r & 3) + 8 * (r >> 2);
+          float v = acc[j][r];
+          if constexpr (kTwoAcc) v += acc2[j][r];
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (!keep) v = 0.f;
+          if (a.res && row0 < M) v += bload1(r_rs, r_voff, (unsigned)(row0 + k) * rowT);
+          if (row0 >= M) v = 0.f;
+          acc[j][r] = v;
+          part += v;
+        }
+      }
+      part += __shfl_xor(part, 32);
+      float* red = lds;                                                // [2][4 waves][32 frames]
+      __syncthreads();                                                 // every wave is done with the input window
+      if (hl == 0) red[wave * 32 + l31] = part;
+      __syncthreads();
+      const float mean = (red[l31] + red[32 + l31] + red[64 + l31] + red[96 + l31]) / (float)M;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        if (row0 < M) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float d = acc[j][r] - mean; sq += d * d; }
+        }
+      }
+      sq += __shfl_xor(sq, 32);
+      if (hl == 0) red[128 + wave * 32 + l31] = sq;
+      __syncthreads();
+      const float var = (red[128 + l31] + red[160 + l31] + red[192 + l31] + red[224 + l31]) / (float)M;
+      const float rstd = rsqrtf(var + 1e-5f);
+      const float lm = (a.ln_out_lens && t >= a.ln_out_lens[b]) ? 0.f : 1.f;
+      const unsigned bvo = (unsigned)(4 * hl) * 4u;
+#pragma unroll
+      for (int j = 0; j < NRT; ++j) {
+        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        if (row0 >= M) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gq = bload4(g_rs, bvo, (unsigned)(row0 + 8 * q) * 4u), bq = bload4(be_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+            bstore1(((acc[j][4 * q + s2] - mean) * rstd * gq[s2] + bq[s2]) * lm, y_rs, y_voff, (unsigned)(row0 + 8 * q + s2) * rowT);
+        }
+      }
+    } else
     // ---- stores (masked lanes' stores are dropped by the range check) ------------------------------
     {
       const bool keep = !a.out_lens || t < a.out_lens[b];
@@ -296,6 +356,7 @@ void launch_narrow_epi(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
   switch (a.epi) {
     case EPI_STORE: launch_narrow_t<NRT, EPI_STORE>(a, gm, s); break;
     case EPI_RESID: launch_narrow_t<NRT, EPI_RESID>(a, gm, s); break;
+    case EPI_LN: launch_narrow_t<NRT, EPI_LN>(a, gm, s); break;
     default: launch_narrow_t<NRT, EPI_RESID_ACC>(a, gm, s); break;
   }
 }
@@ -305,7 +366,8 @@ void launch_narrow_epi(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
 // What the narrow kernel covers: the three plain epilogues, rows in whole 32-row tiles, no reflect
 // padding, tensors addressable with 32-bit byte offsets.
 bool conv1d_narrow_supported(const ConvArgs& a) {
-  if (a.epi != EPI_STORE && a.epi != EPI_RESID && a.epi != EPI_RESID_ACC) return false;
+  if (a.epi != EPI_STORE && a.epi != EPI_RESID && a.epi != EPI_RESID_ACC && a.epi != EPI_LN) return false;
+  if (a.epi == EPI_LN && (a.M > 768 || !a.ln_gamma || !a.ln_beta)) return false;      // one row block holds every channel
   if (a.reflect1 || a.M % 32 || a.Cin % 8 || a.K < 1 || a.K > 11) return false;
   if (a.x_rstride != a.Tin && a.x_rstride < a.Tin) return false;
   const unsigned long long lim = 1ull << 31;
@@ -319,6 +381,7 @@ bool conv1d_narrow_supported(const ConvArgs& a) {
 // smaller workgroups for single utterances).  false: from M alone, so that the summation order of a
 // row never depends on what else is in the batch (the default mode's bitwise batch independence).
 void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s) {
+  if (a.epi == EPI_LN) by_launch_size = false;       // the LayerNorm needs the whole height in one workgroup
   NarrowGeom gm;
   gm.hpu = (a.T + kHalf - 1) / kHalf;
   gm.n_ctiles = (int)(((long)a.B * gm.hpu + 1) / 2);

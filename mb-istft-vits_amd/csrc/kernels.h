@@ -20,6 +20,9 @@ enum ConvEpilogue : int {
                      // output phases: rows come in groups of 64 = 64/U channels x (first U/2 phases | last
                      // U/2 phases); tap 0 is all-zero for the second half, the last tap for the first
                      // (their MFMAs are skipped); a lane stores y[co, U t .. U t + U - 1]
+  EPI_LN = 7,        // conv1d_narrow.hip only (T <= 256, M <= 768): y = LN_c( relu?(acc + bias) * out_mask + res ) * gamma + beta
+                     // [* ln_mask]: the conv that feeds a channel LayerNorm and that LayerNorm in one launch
+                     // (attentions.py:40-46 conv_o / ffn -> norm(x + y); models.py:128-135 conv -> relu -> norm)
 };
 
 struct ConvArgs {
@@ -70,6 +73,10 @@ struct ConvArgs {
   int n_counters;
   int convt_u;             // EPI_CONVT: upsampling stride (4 or 8)
   int splitk;              // 1: split-K allowed for this launch (mbv_set_option "splitk" / MBV_CONV_SPLITK)
+  // EPI_LN
+  const float* ln_gamma;   // [M]
+  const float* ln_beta;    // [M]
+  const int* ln_out_lens;  // mask behind the LayerNorm (the encoder's last layer), or nullptr
 };
 void launch_conv1d(const ConvArgs& a, hipStream_t s);
 bool conv1d_supported(int K, int dil);   // kernel sizes / dilations the MFMA kernel is built for
