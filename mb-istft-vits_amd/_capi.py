@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmbistft_vits.so")
+# MBV_LIB: another build of the same library (A/B measurements of compile-time switches, scripts/stage_ab.py)
+LIB_PATH = os.environ.get("MBV_LIB") or os.path.join(CSRC, "libmbistft_vits.so")
 
 # every symbol include/mbistft_vits.h declares
 SYMBOLS = [

@@ -41,6 +41,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef MBV_CONV_GLDS
+#define MBV_CONV_GLDS 8      // widest channel chunk CK whose 512-thread kernels take their weights by LDS-DMA (0: none; A/B builds)
+#endif
 namespace mbv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -197,7 +200,13 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   constexpr int RPI = NT / BM;                                 // weight rows [BM x f32x4] per pass
   constexpr int ROWS_PER_TAP = 2 * G;
   static_assert(RPI % ROWS_PER_TAP == 0 || ROWS_PER_TAP % RPI == 0, "weight-row decomposition");
-  f32x4 wreg[NW];
+  // 512-thread shape: the weight slab goes global -> LDS by LDS-DMA (no registers: the kernel sits at the
+  // 256-register cap), see MBV_GLDS_W; the 256-thread shapes stage it through wreg
+  // Only the CK = 8 kernels (k = 7 / 11): their MFMA loop (9 - 14 us) covers the DMA issued at its top.
+  // With CK = 16 (k = 3, 4 us per chunk) the same change measured +5 % (489 -> 516 us): register staging
+  // issues a chunk's weights one barrier EARLIER and so has two loops to land them.
+  constexpr bool GLDS = DB && CK <= MBV_CONV_GLDS;
+  f32x4 wreg[GLDS ? 1 : NW];
   f32x4 xreg[NXP];
   int xoff[NXP];
   const int totalW = a.K * ROWS_PER_TAP * BM;                  // float4 in the slab
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   {                                                                                          \
     const int cn_ = (CN);                                                                    \
     const float* wchunk = wlane + (int64_t)(cn_ / 8) * 2 * a.Mpad * 4;                       \
+    if constexpr (!GLDS) {                                                                   \
     _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
       int64_t off;                                                                           \
       if constexpr (RPI >= ROWS_PER_TAP) {                                                   \
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
         off = tap * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad * 4;                    \
       }                                                                                      \
       wreg[u] = *reinterpret_cast<const f32x4*>(wchunk + off);                               \
+    }                                                                                        \
     }                                                                                        \
     const float* xchunk = xb + (int64_t)cn_ * a.x_rstride;                                   \
     const unsigned rs2 = 2u * (unsigned)a.x_rstride;                                         \
@@ -272,9 +283,11 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 #define MBV_COMMIT(CN, XS, WS)                                                               \
   {                                                                                          \
     const int cn_ = (CN);                                                                    \
+    if constexpr (!GLDS) {                                                                   \
     _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
       const int e = tid + NT * u;                                                            \
       if (e < totalW) (WS)[e] = wreg[u];           /* LDS order == copy order */             \
+    }                                                                                        \
     }                                                                                        \
     int P = tid / XL, col = tid - P * XL;                                                    \
     _Pragma("unroll") for (int u = 0; u < NXP; ++u) {                                        \
@@ -295,6 +308,39 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
         if (col >= XL) { col -= XL; ++P; }                                                   \
     }                                                                                        \
   }
+
+  // Weight slab of chunk CN by LDS-DMA: pass u of a wave is 64 consecutive float4 of the slab, in LDS at
+  // float4 index (tid & ~63) + NT u — a wave-uniform base + lane * 16 B, which is what
+  // global_load_lds_dwordx4 writes.  Issued right after the barrier that retired the last readers of WS,
+  // lands under the MFMA loop of the current chunk.  Written as asm on purpose: with the builtin hipcc
+  // (ROCm 7.2) drains the whole vector-memory queue at every barrier of the loop — including the input
+  // window loads of the chunk after, issued just before it — and the kernel was 2 % SLOWER than register
+  // staging.  hipcc does not count asm memory operations, so the ordering is explicit: MBV_GLDS_DRAIN
+  // (s_waitcnt vmcnt(0), after the MFMA loop, when the DMA has long landed) before the chunk's barrier,
+  // the readers start after that barrier.
+#define MBV_GLDS_W(CN, WS)                                                                   \
+  {                                                                                          \
+    const float* wchunk = wlane + (int64_t)((CN) / 8) * 2 * a.Mpad * 4;                      \
+    const int wave_e0 = __builtin_amdgcn_readfirstlane(tid & ~63);                           \
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(                                    \
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)((WS) + wave_e0));        \
+    _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
+      int64_t off;                                                                           \
+      if constexpr (RPI >= ROWS_PER_TAP) {                                                   \
+        off = (int64_t)(u * (RPI / ROWS_PER_TAP)) * tap_stride;                              \
+      } else {                                                                               \
+        constexpr int PPT = ROWS_PER_TAP / RPI;                                              \
+        off = (u / PPT) * tap_stride + (int64_t)((u % PPT) * RPI) * a.Mpad * 4;              \
+      }                                                                                      \
+      if (wave_e0 + NT * u < totalW) {           /* wave-uniform: rows past the slab */      \
+        unsigned keep_m0;                                                                    \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                  \
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                   \
+                     : "=&s"(keep_m0) : "v"(wchunk + off), "s"(lds0 + (unsigned)(NT * u * 16)) : "memory"); \
+      }                                                                                      \
+    }                                                                                        \
+  }
+#define MBV_GLDS_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   // staging cursor: the next chunk to load (runs ahead of the tile being multiplied)
   const int nck = a.Cin / CK;
@@ -329,9 +375,13 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   {
     f32x4* const X0 = lds4;
     f32x4* const W0 = X0 + G * 2 * XL;
-    if (pend_cn >= 0) { MBV_COMMIT(pend_cn, X0, W0); }
+    if (pend_cn >= 0) {
+      if constexpr (GLDS) { MBV_GLDS_W(pend_cn, W0); }
+      MBV_COMMIT(pend_cn, X0, W0);
+    }
     pend_cn = -1;
   }
+  if constexpr (GLDS) { MBV_GLDS_DRAIN(); }
   __syncthreads();
 
   int q = 0;                             // chunks multiplied so far (LDS buffer parity)
@@ -392,6 +442,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
       f32x4* const Xn = lds4 + (DB ? ((q & 1) ? 0 : buf_f4) : 0);           // buffer for the next one
       f32x4* const Wn = Xn + G * 2 * XL;
       if constexpr (!DB) { MBV_ISSUE_NEXT(); }       // next chunk (possibly the next tile's first)
+      if constexpr (GLDS) {
+        if (pend_cn >= 0) { MBV_GLDS_W(pend_cn, Wn); }   // its input window is already in flight (xreg)
+      }
 
       if (a.debug != 3) {
         // ---- MFMA over (tap, group) steps; each step = 4 K-steps from one b128 per operand tile
@@ -475,6 +528,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
       if constexpr (DB) {
         if (pend_cn >= 0) { MBV_COMMIT(pend_cn, Xn, Wn); }   // other buffer: last read one barrier ago
         pend_cn = -1;
+        if constexpr (GLDS) { MBV_GLDS_DRAIN(); }            // this wave's share of the next weight slab has landed
         if (c + 1 < c_hi) { MBV_ISSUE_NEXT(); }              // the last chunk issues AFTER the epilogue
         __syncthreads();
       } else {
@@ -690,6 +744,8 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 #undef MBV_SETUP_TILE
 #undef MBV_ISSUE
 #undef MBV_COMMIT
+#undef MBV_GLDS_W
+#undef MBV_GLDS_DRAIN
 }
 
 template <int WM, int WN, int CK, int NWN, int EPI>

@@ -1,6 +1,8 @@
 """-m gpu: kernel-level parity through the C-ABI.
 fp32 tolerances: conv sums of <= 8448 products -> 2e-5 relative to the output RMS;
 iSTFT+PQMF -> 2e-5 absolute on O(1) signals (north-star bar on the waveform is 1e-4 RMS)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -338,3 +340,25 @@ def test_reference_side_binding_runs_against_golden():
         assert set(timings) == {"text_encoder", "duration_predictor", "alignment_and_projection", "flow", "waveform_decoder"}
         do = net.decode(z[:, :, :20].contiguous(), None if sid is None else torch.from_numpy(sd["emb_g.weight"])[gold["sid"]].cuda())[0]
         assert do.shape == (z.shape[0], 1, 256 * 20) and torch.isfinite(do).all()
+
+
+@pytest.mark.timeout(600)
+def test_fused_wn_layer_kernel_against_cpu_loop(tmp_path):
+    """`wn_layer_kernel` (wn_fused.hip) on its own against a plain CPU loop in float64
+    (`scripts/wn_layer_check.hip` includes the kernel source and is compiled here with hipcc):
+    ragged lengths, tiles that span two utterances, the last layer's 6-tile res/skip GEMM (idle tile
+    slots must not store into the next utterance), 64 / 96 / 160 / 192 channels."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "wn_layer_check")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "mb-istft-vits_amd", "csrc"),
+                        os.path.join(root, "scripts", "wn_layer_check.hip"), "-o", exe], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for args in (["3", "96", "45", "0", "45", "41", "15"], ["2", "96", "48", "0", "48", "48"], ["5", "192", "70", "1"],
+                 ["5", "192", "70", "0"], ["3", "64", "33", "0"], ["4", "160", "50", "1"], ["2", "96", "74", "0", "61", "74"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (args, r.stdout[-1500:], r.stderr[-500:])
