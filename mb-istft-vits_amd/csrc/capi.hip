@@ -955,8 +955,8 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
 // Fused path (default): one launch per layer over the units that hold valid frames, h ping-pongs
 // between hbuf and acts (the old path's gated-activation buffer); afterwards only `skip` is meaningful,
 // and only where the frame mask is 1 (every reader masks on load).
-// Two-launch path (MBV_WN_FUSED=0, or small launches in the low-latency split-K mode, where one
-// workgroup per 32-frame unit would leave most of the chip idle): gate conv, then res/skip conv.
+// Two-launch path (MBV_WN_FUSED=0; experiments: MBV_WN_SMALL=<tiles> in the low-latency mode): gate conv,
+// then res/skip conv.
 int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16_l, const PConv* rsp_l, int nl,
            const PVec& cw, const PVec& cb, const float* gvec, float* hbuf, float* acts, float* skip, float* gc,
            int* ustart, const int* lens, int B, int T, hipStream_t s) {
@@ -965,7 +965,11 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
   const int64_t bsH = (int64_t)H * T;
   const bool cond = gvec && gin && cw.present;
   if (cond) launch_cond_gemv(gvec, nullptr, nullptr, m->W(cw.off), m->W(cb.off), gc, B, gin, 2 * H * nl, s);
-  const bool small = (long)B * ((T + 31) / 32) < 192;
+  // (r02f: the fused layer wins or ties at every size measured, down to one utterance = 9 workgroups —
+  // ljs_mini B=1 3.55 -> 3.11 ms, B=8 4.33 -> 3.68, ljs_mb B=8 9.69 -> 9.04, B=1 5.10 -> 5.14 — so the
+  // two-launch path is only taken when MBV_WN_SMALL asks for it: launches below that many 32-frame tiles)
+  static const int small_units = [] { const char* e = getenv("MBV_WN_SMALL"); return e ? atoi(e) : 0; }();
+  const bool small = (long)B * ((T + 31) / 32) < small_units;
   if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small)) {
     int* hmap = ustart + B + 1;
     launch_wn_units(lens, B, T, ustart, hmap, s);
@@ -1243,7 +1247,9 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, bad, B, T, H, c.n_vocab, s);
   const int64_t bsH = (int64_t)H * T;
   static const int fuse_ln_env = [] { const char* e = getenv("MBV_FUSE_LN"); return e ? atoi(e) : 1; }();
-  const bool fuse_ln = fuse_ln_env && T <= 256;        // (a rule on T alone: rows stay batch-independent)
+  // (a rule on T alone: rows stay batch-independent; the opt-in low-latency mode may look at the launch
+  // size: fused, a conv + LayerNorm is one workgroup per 32 frames walking the whole K loop alone)
+  const bool fuse_ln = fuse_ln_env && T <= 256 && !(m->splitk && (long)B * ((T + 15) / 16) < 128);
   for (int i = 0; i < c.n_layers; ++i) {
     const auto& L = m->enc[i];
     launch_conv1d(conv_args(m, L.qkv, x, bsH, T, qkv, 3 * bsH, T, B), s);

@@ -46,12 +46,25 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsig
 }
 __device__ __forceinline__ float lrelu_(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// In-kernel timeline (scripts/narrow_stamps.hip builds this file with -DMBV_NARROW_STAMPS): wave 0 of every
+// workgroup writes the 100 MHz wall clock at the phase boundaries of its first unit into a.ws.
+#ifdef MBV_NARROW_STAMPS
+#define MBV_STAMP(I)                                                                          \
+  if (tid == 0 && u == (int)blockIdx.x) reinterpret_cast<unsigned long long*>(a.ws)[blockIdx.x * 8 + (I)] = __builtin_amdgcn_s_memrealtime();
+#define MBV_CYCLES(I)                                                                         \
+  if (tid == 0 && u == (int)blockIdx.x) reinterpret_cast<unsigned long long*>(a.ws)[blockIdx.x * 8 + (I)] = __builtin_readcyclecounter();
+#else
+#define MBV_STAMP(I)
+#define MBV_CYCLES(I)
+#endif
+
 struct NarrowGeom {
   int hpu;        // half-units per utterance: ceil(T / 16)
   int n_ctiles;   // column tiles: ceil(B hpu / 2)
   int n_rblk;     // row blocks of 128 NRT rows
   int CB;         // channels per staged block (multiple of 8, divides Cin)
   int XS;         // column stride of a half-unit's window in the LDS image (multiple of 16, >= 16 + halo)
+  int pf_period;  // lcm(8, n_rblk): workgroups blockIdx = i (mod pf_period) share an XCD and a row block
 };
 
 template <int NRT, int EPI>
@@ -79,11 +92,36 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
   const unsigned w_step = (unsigned)(2 * a.Mpad * 16);                 // bytes per (tap, group) step
   const unsigned rowT = (unsigned)T * 4u;
 
+  // Weight prefetch into this XCD's L2.  A single utterance is ~130 workgroups that all stream the SAME
+  // weights (0.2 - 1.8 MB per conv, read once per infer, so they come from the Infinity Cache / HBM) through
+  // a ring that looks ~1 us ahead: the whole launch advances at one memory latency per ring depth (measured:
+  // 46 - 50 us for 12 us of MFMA work).  So before anything else the workgroups of one XCD that share a row
+  // block touch that row block's weight lines once, spread over their threads (one 128-byte line per load,
+  // kPF loads per thread): the K loop then streams from L2.  The values are never used (the empty asm at
+  // the end only keeps the loads alive; they return in order, long before anything waits for them).
+  constexpr int kPF = 4;
+  float pfv[kPF];
+  {
+    const int lpr = 16 * NRT;                                          // 128-byte lines per (tap, group, h) run of a row block
+    const int n_lines = K * G * 2 * lpr;
+    const int first_rb = blockIdx.x % gm.n_rblk;
+    const int jj = blockIdx.x / gm.pf_period;
+    const int n_same = (gridDim.x - blockIdx.x % gm.pf_period + gm.pf_period - 1) / gm.pf_period;
+#pragma unroll
+    for (int i = 0; i < kPF; ++i) {
+      const int idx = (jj + i * n_same) * 256 + tid;
+      const int run = idx / lpr, within = idx - run * lpr;
+      const unsigned vo = idx < n_lines ? (unsigned)((run * a.Mpad + first_rb * 128 * NRT) * 16 + within * 128) : kOob;
+      pfv[i] = bload1(w_rs, vo, 0);
+    }
+  }
+
   // A ring: kD slots, loads run kD - 1 steps ahead.  A step is 4 NRT MFMAs (256 NRT cycles), the ring has
   // to cover an L2 round trip (~1-2 k cycles under load): deep for one row tile per wave, shallow for six.
   constexpr int kD = NRT == 1 ? 12 : (NRT == 2 ? 8 : 4);
   const int n_units = gm.n_ctiles * gm.n_rblk;
   for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+    MBV_STAMP(0)
     const int ct = u / gm.n_rblk, rb = u - ct * gm.n_rblk;
     // the two half-units: utterance, first frame, "exists"
     int hb[2], ht0[2], hok[2];
@@ -133,35 +171,46 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       }
     }
 
-    constexpr bool kTwoAcc = NRT <= 2;
-    f32x16 acc2[kTwoAcc ? NRT : 1];
+    MBV_STAMP(1)
+    // Independent MFMA chains per wave.  A 32x32x2 fp32 MFMA occupies the pipe for 64 cycles but its result
+    // feeds the next MFMA on the same accumulator only ~250 cycles later (scripts/narrow_stamps.hip: with one
+    // workgroup per CU, two chains ran at 132 cycles per MFMA, four at 60), so a wave needs four accumulators
+    // in flight: the K-steps of a group go round-robin over kExtra + 1 accumulator sets per row tile, summed
+    // before the epilogue.
+    constexpr int kExtra = NRT == 1 ? 3 : (NRT == 2 ? 1 : 0);
+    constexpr bool kTwoAcc = kExtra > 0;
+    f32x16 acc2[kTwoAcc ? kExtra * NRT : 1];
     if constexpr (kTwoAcc) {
 #pragma unroll
-      for (int j = 0; j < NRT; ++j)
+      for (int j = 0; j < kExtra * NRT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
     }
     for (int blk = 0; blk < nblk; ++blk) {
       const int g0 = blk * GB;
-      // ---- A ring: the first kD - 1 steps of this block (step = g * K + tap inside the block) ----
+      // ---- A ring: the first kD - 1 steps of this block (step = g * K + tap inside the block).  The step
+      // cursors advance by additions only (a wave has 4 NRT MFMAs per step to hide its scalar work behind,
+      // and with one wave per SIMD nothing else hides it: the multiply / clamp form of this bookkeeping
+      // cost ~500 cycles per step, twice the MFMA time of one row tile).  Loads that run past the block
+      // read the next block's weights or, past the tensor, zeros (buffer range check): never used.
       f32x4 ra[kD][NRT];
-      {
-        int tap = 0, gl = 0;
+      const unsigned dWt = (unsigned)G * w_step, dWw = w_step - (unsigned)K * dWt;   // (the wrap comes on top of a tap step)
+      unsigned so = (unsigned)g0 * w_step;
+      int ltap = 0;
+#define MBV_ADV_W() { so += dWt; if (++ltap == K) { ltap = 0; so += dWw; } }
 #pragma unroll
-        for (int d = 0; d < kD - 1; ++d) {
-          const unsigned so = (unsigned)(tap * G + g0 + gl) * w_step;
+      for (int d = 0; d < kD - 1; ++d) {
 #pragma unroll
-          for (int j = 0; j < NRT; ++j) ra[d][j] = bload4(w_rs, w_voff, so + j * 2048u);
-          if (++tap == K) { tap = 0; ++gl; }
-          if (gl >= GB) { gl = GB - 1; tap = K - 1; }                 // fewer steps than slots: harmless re-load
-        }
+        for (int j = 0; j < NRT; ++j) ra[d][j] = bload4(w_rs, w_voff, so + j * 2048u);
+        MBV_ADV_W()
       }
       __syncthreads();                                                 // the previous block's / unit's readers of Xs are done
+      if (blk == 0) { MBV_STAMP(2) }
       // ---- input window of this channel block: [GB][2][2 XS], activated, masked.  The loads of NXI
       // items per thread are all issued before the first is used (one memory latency per batch
       // instead of one per item: at batch 1 a workgroup has nothing else to hide them behind).
       {
-        constexpr int NXI = NRT <= 2 ? 16 : (NRT <= 4 ? 8 : 4);
+        constexpr int NXI = NRT <= 4 ? 8 : 4;
         const int items = GB * 2 * XL;
         const unsigned rs2 = 2u * (unsigned)a.x_rstride * 4u;
         for (int e0 = 0; e0 < items; e0 += 256 * NXI) {
@@ -201,57 +250,65 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         }
       }
       __syncthreads();
+      if (blk == 0) { MBV_STAMP(3) MBV_CYCLES(6) }
 
       // ---- MFMA over the block's (group, tap) steps ----------------------------------------------
       {
+        static_assert(kD % 2 == 0, "the B operand ping-pongs between two registers by step parity");
         const f32x4* xl = Xs + hl * XL + xoff;
-        int tap = 0, gl = 0;              // step being multiplied
-        int ltap = 0, lgl = 0;            // step whose A operands are loaded next (kD - 1 ahead)
-#pragma unroll
-        for (int d = 0; d < kD - 1; ++d) { if (++ltap == K) { ltap = 0; ++lgl; } }
-        f32x4 bv = xl[0];
+        const int dXw = 2 * XL - K * a.dil, xo_max = (GB - 1) * 2 * XL + (K - 1) * a.dil;
+        int xo = 0, ntap = 0;             // window offset of the step after the one being multiplied
+#define MBV_ADV_X() { xo += a.dil; if (++ntap == K) { ntap = 0; xo += dXw; } }
+        f32x4 bvv[2];
+        bvv[0] = xl[0];
+        MBV_ADV_X()
         for (int s0 = 0; s0 < steps_blk; s0 += kD) {
 #pragma unroll
           for (int d = 0; d < kD; ++d) {
             if (s0 + d < steps_blk) {
-              {
-                const int lg = lgl < GB ? lgl : GB - 1;               // past the block: re-load its last step (unused)
-                const unsigned so = (unsigned)((lgl < GB ? ltap : K - 1) * G + g0 + lg) * w_step;
-#pragma unroll
-                for (int j = 0; j < NRT; ++j) ra[(d + kD - 1) % kD][j] = bload4(w_rs, w_voff, so + j * 2048u);
-                if (++ltap == K) { ltap = 0; ++lgl; }
-              }
-              int ntap = tap + 1, ngl = gl;
-              if (ntap == K) { ntap = 0; ++ngl; }
-              if (ngl >= GB) { ngl = gl; ntap = tap; }
-              const f32x4 bn = xl[ngl * 2 * XL + ntap * a.dil];
-              __builtin_amdgcn_sched_barrier(0);
-              if constexpr (kTwoAcc) {
-                // one row tile per wave is ONE dependent MFMA chain, which does not issue back to back:
-                // the K-steps alternate between two accumulator sets (summed before the stores)
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                  for (int j = 0; j < NRT; ++j) {
-                    if (s4 & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc2[j], 0, 0, 0);
-                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc[j], 0, 0, 0);
-                  }
-              } else {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                  for (int j = 0; j < NRT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][s4], bv[s4], acc[j], 0, 0, 0);
+              // One step = 4 K-steps x NRT row tiles.  The bookkeeping (next ring load, next window read,
+              // cursor arithmetic) is issued BETWEEN the MFMAs: a wave stalls at every MFMA until the pipe
+              // takes it, so scalar work placed there is free, while in front of the first MFMA of a step it
+              // leaves the pipe idle (one wave per SIMD at batch 1).
+#define MBV_MMA(S4)                                                                                         \
+              _Pragma("unroll") for (int j = 0; j < NRT; ++j) {                                             \
+                constexpr int set = (S4) % (kExtra + 1);                                                    \
+                if constexpr (set != 0)                                                                     \
+                  acc2[(set - 1) * NRT + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][S4], bvv[d & 1][S4], acc2[(set - 1) * NRT + j], 0, 0, 0); \
+                else                                                                                        \
+                  acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d][j][S4], bvv[d & 1][S4], acc[j], 0, 0, 0);                                        \
               }
               __builtin_amdgcn_sched_barrier(0);
-              bv = bn;
-              tap = ntap; gl = ngl;
+              MBV_MMA(0)
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int j = 0; j < NRT; ++j) {
+#if defined(MBV_NARROW_STAMPS) && MBV_NARROW_EXP == 1      // timeline experiment: no weight loads inside the loop
+                asm volatile("" : "+v"(ra[(d + kD - 1) % kD][j]) : "s"(so));
+#else
+                ra[(d + kD - 1) % kD][j] = bload4(w_rs, w_voff, so + j * 2048u);
+#endif
+              }
+              MBV_ADV_W()
+              __builtin_amdgcn_sched_barrier(0);
+              MBV_MMA(1)
+              __builtin_amdgcn_sched_barrier(0);
+              bvv[(d + 1) & 1] = xl[min(xo, xo_max)];
+              MBV_ADV_X()
+              __builtin_amdgcn_sched_barrier(0);
+              MBV_MMA(2)
+              MBV_MMA(3)
+              __builtin_amdgcn_sched_barrier(0);
+#undef MBV_MMA
             }
           }
         }
+#undef MBV_ADV_X
+#undef MBV_ADV_W
       }
     }
 
+    MBV_STAMP(4) MBV_CYCLES(7)
     if constexpr (EPI == EPI_LN) {
       // ---- conv -> (relu) -> (mask) -> + residual -> channel LayerNorm -> affine -> (mask): the workgroup
       // holds every channel of its 32 frames (one row block), the statistics of a frame are reduced over
@@ -268,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         for (int r = 0; r < 16; ++r) {
           const int k = (r & 3) + 8 * (r >> 2);
           float v = acc[j][r];
-          if constexpr (kTwoAcc) v += acc2[j][r];
+          if constexpr (kExtra == 1) v += acc2[j][r];
+          if constexpr (kExtra == 3) v = (v + acc2[j][r]) + (acc2[NRT + j][r] + acc2[2 * NRT + j][r]);
           if (a.relu) v = fmaxf(v, 0.f);
           if (!keep) v = 0.f;
           if (a.res && row0 < M) v += bload1(r_rs, r_voff, (unsigned)(row0 + k) * rowT);
@@ -323,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         for (int r = 0; r < 16; ++r) {
           const int k = (r & 3) + 8 * (r >> 2);
           float v = acc[j][r];
-          if constexpr (kTwoAcc) v += acc2[j][r];
+          if constexpr (kExtra == 1) v += acc2[j][r];
+          if constexpr (kExtra == 3) v = (v + acc2[j][r]) + (acc2[NRT + j][r] + acc2[2 * NRT + j][r]);
           if constexpr (EPI == EPI_STORE) {
             if (a.relu) v = fmaxf(v, 0.f);
             if (!keep) v = 0.f;
@@ -334,7 +393,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         }
       }
     }
+    MBV_STAMP(5)
   }
+#pragma unroll
+  for (int i = 0; i < kPF; ++i) asm volatile("" ::"v"(pfv[i]));
 }
 
 template <int NRT, int EPI>
@@ -400,6 +462,8 @@ void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s)
   if (nrt > 6) nrt = 6;
   while (by_launch_size && nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
   gm.n_rblk = (tiles_m + 4 * nrt - 1) / (4 * nrt);
+  gm.pf_period = 8;
+  while (gm.pf_period % gm.n_rblk) gm.pf_period += 8;               // lcm(8, n_rblk)
   switch (nrt) {
     case 1: launch_narrow_epi<1>(a, gm, s); break;
     case 2: launch_narrow_epi<2>(a, gm, s); break;
