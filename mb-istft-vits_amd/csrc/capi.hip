@@ -103,6 +103,11 @@ struct mbv_model {
 
   hipEvent_t ev[7]{};
   hipEvent_t evk[3]{};          // decoder start / before istft / after istft
+  // the three ResBlocks of a decoder stage on three streams when one of them cannot fill the chip (run_decoder)
+  hipStream_t aux[2]{};
+  hipEvent_t ev_fork{}, ev_rb[3]{};
+  bool aux_ok = false;
+  int dec_streams = 1;          // option "dec_streams" / MBV_DEC_STREAMS: 0 = always one stream
   bool ev_ok = false, ev_a = false, ev_b = false, evk_set = false;
 
   int fail(const char* fmt, ...) {
@@ -791,10 +796,21 @@ ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x
 }
 
 // decoder + waveform tail on z [B, I, zstride] (first Td frames valid)
+size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td);
+
+// The three ResBlocks of a decoder stage on three streams?  Only when one of their convs (ch channels, Lo
+// frames) is at most 192 tiles of 128 x 384, i.e. cannot fill the chip by itself.
+bool decoder_stage_concurrent(const mbv_model* m, int B, int ch, int Lo) {
+  const long conv_tiles = (long)B * ((Lo + 383) / 384) * ((ch + 127) / 128);
+  return m->dec_streams && m->aux_ok && m->cfg.resblock_type != 2 && conv_tiles <= 192;
+}
+
 int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, const float* gvec,
                 int B, int Td, const mbv_outputs* outs, hipStream_t s, Bump& sc) {
   const mbv_config& c = m->cfg;
   const int I = c.inter_channels, C0 = c.upsample_initial_channel, gin = c.gin_channels;
+  hipStream_t const s_main = s;
+  if (sc.off + decoder_scratch_bytes(c, B, Td) > sc.cap) return m->fail("internal error: decoder scratch arena undersized");
   float* x0 = sc.take<float>((size_t)B * C0 * Td);
   HIPCHK(m, hipEventRecord(m->evk[0], s));
   {
@@ -814,8 +830,18 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
     const int Lo = us * L;
     const size_t n = (size_t)B * ch * Lo;
     float* u = sc.take<float>(n);
-    float* t1 = sc.take<float>(n);
-    float* r = sc.take<float>(n);
+    // The three ResBlocks of a stage read the same input and only meet in the running sum xs.  When one
+    // of their convs cannot fill the chip (single utterances, small batches: decoder_stage_concurrent)
+    // they run on three streams — own temporaries each, the three xs updates chained by events in the
+    // order of the one-stream schedule, so the result is bitwise the same.
+    const bool conc = decoder_stage_concurrent(m, B, ch, Lo);
+    float *t1s[3], *rs[3];
+    t1s[0] = sc.take<float>(n);
+    rs[0] = sc.take<float>(n);
+    for (int j = 1; j < 3; ++j) {
+      t1s[j] = conc ? sc.take<float>(n) : t1s[0];
+      rs[j] = conc ? sc.take<float>(n) : rs[0];
+    }
     xs = sc.take<float>(n);
     static const int convt_as_conv = [] { const char* e = getenv("MBV_CONVT_AS_CONV"); return e ? atoi(e) : 1; }();
     if (m->upc[i].M && convt_as_conv) {
@@ -834,8 +860,23 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       launch_convt(a, s);
     }
     m->stages[i == 0 ? "dec_up_0" : "dec_up_1"] = {u, (int64_t)n};
+    if (conc) {
+      HIPCHK(m, hipEventRecord(m->ev_fork, s_main));
+      for (auto& st : m->aux) HIPCHK(m, hipStreamWaitEvent(st, m->ev_fork, 0));
+    }
     for (int j = 0; j < 3; ++j) {
       const auto& R = m->rb[i * 3 + j];
+      hipStream_t s = (conc && j > 0) ? m->aux[j - 1] : s_main;   // this ResBlock's stream
+      float* const t1 = t1s[j];
+      float* const r = rs[j];
+      // split-K scratch (low-latency mode): a third each, so that concurrent convs never share partials or tickets
+      auto own_ws = [&](ConvArgs& a) {
+        if (!conc) return;
+        const size_t third = a.ws_floats / 3;
+        const int cthird = a.n_counters / 3;
+        a.ws += (size_t)j * third; a.ws_floats = third;
+        a.counters += (size_t)j * cthird; a.n_counters = cthird;
+      };
       const float* cadd = nullptr;
       if (gvec && gin && R.cw.present) {           // x = x + cond(g)   (modules.py:214-215)
         float* cb = sc.take<float>((size_t)B * ch);
@@ -870,6 +911,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
           ConvArgs a = conv_args(m, R.c1[q], state, (int64_t)ch * Lo, Lo, t1, (int64_t)ch * Lo, Lo, B, d);
           a.in_slope = kLrelu;
           if (q == 0) a.chan_add = cadd;
+          own_ws(a);
           launch_conv1d(a, s);
         }
         {
@@ -884,12 +926,16 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
             a.y = xs;
             a.accum_in = j == 0 ? nullptr : xs;
             a.out_scale = j == 2 ? (1.f / 3.f) : 1.f;
+            if (conc && j > 0) HIPCHK(m, hipStreamWaitEvent(s, m->ev_rb[j - 1], 0));   // xs of the ResBlock before
           }
+          own_ws(a);
           launch_conv1d(a, s);
+          if (conc && q == 2) HIPCHK(m, hipEventRecord(m->ev_rb[j], s));
         }
         state = r;
       }
     }
+    if (conc) HIPCHK(m, hipStreamWaitEvent(s_main, m->ev_rb[2], 0));
     m->stages[i == 0 ? "dec_res_0" : "dec_res_1"] = {xs, (int64_t)n};
     cur = xs;
     L = Lo;
@@ -1038,10 +1084,16 @@ size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td) {
   const size_t C0 = c.upsample_initial_channel;
   const size_t us = c.decoder == MBV_DEC_SINGLEBAND ? 8 : 4;
   size_t n = (size_t)B * C0 * Td;                              // conv_pre
-  n += 4 * (size_t)B * (C0 / 2) * us * Td + 4 * (size_t)B * (C0 / 4) * us * us * Td;
+  // per stage: u, t1, r, xs — and t1, r twice more when the ResBlocks may run on three streams (small
+  // launches only; sized for it whenever the tile test can pass, whatever the option says)
+  for (int i = 0; i < 2; ++i) {
+    const size_t ch = C0 >> (i + 1), Lo = (i == 0 ? us : us * us) * (size_t)Td;
+    const long conv_tiles = (long)B * (long)((Lo + 383) / 384) * (long)((ch + 127) / 128);
+    n += (conv_tiles <= 192 ? 8 : 4) * (size_t)B * ch * Lo;
+  }
   n += (size_t)B * 72 * (us * us * Td + 1) + (size_t)B * 256 * Td;
   n += 6 * (size_t)B * C0;                                     // cond vectors
-  return n * sizeof(float) + 64 * 256;
+  return n * sizeof(float) + 64 * 256 + 32 * 256;              // + the 256-byte alignment of every take
 }
 
 }  // namespace
@@ -1101,6 +1153,14 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   for (auto& e : m->evk)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   m->ev_ok = true;
+  { const char* e = getenv("MBV_DEC_STREAMS"); m->dec_streams = e ? (atoi(e) != 0) : 1; }
+  {
+    bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : m->ev_rb) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    for (auto& st : m->aux) ok = ok && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { delete m; return bad("creating the decoder's auxiliary streams failed"); }
+    m->aux_ok = true;
+  }
   {   // split-K scratch of small conv launches: 64 MB of partials, 8192 ticket counters (zeroed once;
       // the kernel resets a counter when its last split has arrived)
     constexpr size_t kWsFloats = (size_t)16 << 20;
@@ -1125,7 +1185,8 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!strcmp(name, "istft_exact")) { m->exact_math = value != 0; return 0; }
   if (!strcmp(name, "wn_fused")) { m->wn_fused = value != 0; return 0; }
   if (!strcmp(name, "xpost_chunk_bytes")) { m->xpost_chunk_bytes = value > 0 ? value : 0; return 0; }
-  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes)", name);
+  if (!strcmp(name, "dec_streams")) { m->dec_streams = value != 0; return 0; }
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams)", name);
 }
 
 void mbv_destroy(mbv_model* m) {
@@ -1139,6 +1200,11 @@ void mbv_destroy(mbv_model* m) {
   if (m->user_tab) (void)hipFree(m->user_tab);
   if (m->peak_buf) (void)hipFree(m->peak_buf);
   if (m->ev_ok) { for (auto& e : m->ev) (void)hipEventDestroy(e); for (auto& e : m->evk) (void)hipEventDestroy(e); }
+  if (m->aux_ok) {
+    for (auto& st : m->aux) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    (void)hipEventDestroy(m->ev_fork);
+    for (auto& e : m->ev_rb) (void)hipEventDestroy(e);
+  }
   delete m;
 }
 

@@ -130,10 +130,20 @@ __global__ __launch_bounds__(256) void durations_kernel(const float* h, const fl
       float lw = 0.f, wc = 0.f;
       if (t < len) {
         if (w) {
-          float acc = 0.f;
+          // four interleaved partial sums: one dependent fmaf chain over 256 channels behind 256 loads was
+          // 63 us per launch, as long as a text-encoder conv
+          float acc4[4] = {0.f, 0.f, 0.f, 0.f};
           const float* hp = h + (int64_t)b * C * T + t;
-          for (int c = 0; c < C; ++c) acc = fmaf(w[c], hp[(int64_t)c * T], acc);
-          lw = acc + bias[0];
+          int c = 0;
+          for (; c + 8 <= C; c += 8) {
+            float hv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hv[q] = hp[(int64_t)(c + q) * T];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc4[q & 3] = fmaf(w[c + q], hv[q], acc4[q & 3]);
+          }
+          for (; c < C; ++c) acc4[c & 3] = fmaf(w[c], hp[(int64_t)c * T], acc4[c & 3]);
+          lw = ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + bias[0];
         } else {
           lw = h[(int64_t)b * T + t];            // SDP: logw computed by the flows (sdp.hip)
         }
