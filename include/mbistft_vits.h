@@ -152,7 +152,11 @@ int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, v
  *   "xpost_chunk_bytes"  the fused iSTFT kernels address their input with 32-bit byte offsets, so a
  *                  batch whose x_post ([B, 72, F] fp32) would reach 2 GiB runs subband_conv_post +
  *                  iSTFT in sub-batches (same T', bitwise the unsplit result).  This option lowers
- *                  the cap (bytes; 0 = 2 GiB - 1) — tests use it to take the split path at small sizes. */
+ *                  the cap (bytes; 0 = 2 GiB - 1) — tests use it to take the split path at small sizes.
+ *   "dec_streams"  1 (default; MBV_DEC_STREAMS): when one ResBlock conv of a decoder stage cannot fill the
+ *                  chip (single utterances, small batches) the stage's three ResBlocks (models.py:353-359)
+ *                  run on three internal streams forked from / joined to `stream`; bitwise the result of
+ *                  the one-stream schedule (0). */
 int mbv_set_option(mbv_model *m, const char *name, int value);
 
 /* ---- stage timers -----------------------------------------------------------

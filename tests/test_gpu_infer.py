@@ -364,6 +364,33 @@ def test_oversized_batch_is_split_not_refused():
     assert _same_rows(o_s, o[rows]) and _same_rows(spec_s, spec[rows])
 
 
+def test_resblock_streams_are_bitwise_the_one_stream_schedule():
+    """Small launches run the three ResBlocks of a decoder stage on three streams (capi.hip run_decoder):
+    same kernels, the running-sum updates chained in the one-stream order, so every output must be
+    bitwise what `dec_streams = 0` gives — in both modes, all decoder families, repeated (a race between
+    the streams would show as run-to-run differences)."""
+    from gpu_util import make_net
+    rs = np.random.RandomState(21)
+    for cfg_name in ("ljs_mb_istft_vits", "ljs_ms_istft_vits", "ljs_mini_istft_vits", "uudb_ms_istft_vits_ms"):
+        net, sd = make_net(cfg_name)
+        _, cfg = config_for(cfg_name)
+        for B, Tp in ((1, 265), (3, 41)):
+            z = torch.from_numpy(rs.standard_normal((B, cfg.inter_channels, Tp)).astype(np.float32)).cuda()
+            g = None
+            if cfg.gin_channels:
+                g = torch.from_numpy(rs.standard_normal((B, cfg.gin_channels, 1)).astype(np.float32)).cuda()
+            for splitk in (0, 1):
+                net.set_option("splitk", splitk)
+                net.set_option("dec_streams", 0)
+                one = net.dec(z, g=g)
+                net.set_option("dec_streams", 1)
+                for _ in range(3):
+                    three = net.dec(z, g=g)
+                    for a, b in zip(one, three):
+                        assert (a is None and b is None) or torch.equal(a, b), (cfg_name, B, splitk)
+            net.set_option("splitk", 0)
+
+
 def test_voice_conversion_matches_reference_golden():
     """`voice_conversion` (models.py:790-798) against the vector captured from the reference; the
     posterior encoder's noise draw is pinned by seeding torch and recovering it is not possible, so
