@@ -67,7 +67,11 @@ struct NarrowGeom {
   int pf_period;  // lcm(8, n_rblk): workgroups blockIdx = i (mod pf_period) share an XCD and a row block
 };
 
-template <int NRT, int EPI>
+// KS ("K-split pairs"): for heights that four waves split badly (6 row tiles = 2 / 2 / 1 / 1 with a quarter of
+// the MFMAs spent on tiles that do not exist), waves 0 / 1 own row tiles 0 .. NRT-1 / NRT .. 2 NRT-1 of a
+// 64 NRT-row block and waves 2 / 3 the same tiles again: each pair splits the K loop (even / odd steps) and
+// waves 2 / 3 hand their partial sums over through LDS before the epilogue, which waves 0 / 1 run alone.
+template <int NRT, int EPI, bool KS = false>
 __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a, const NarrowGeom gm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   f32x4* const Xs = reinterpret_cast<f32x4*>(lds);                     // [CB / 8][2][2 XS]
@@ -81,6 +85,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
   const int nblk = a.Cin / gm.CB;
   const int steps_blk = GB * K;
   const int n_hu = a.B * gm.hpu;
+  constexpr int kRowsBlk = (KS ? 64 : 128) * NRT;                      // rows of a row block
+  constexpr unsigned kJS = KS ? 512u : 2048u;                          // byte distance of a wave's consecutive row tiles in the packed weights
+  const int tile0 = KS ? (wave & 1) * NRT : wave;                      // a wave's row tiles: tile0 + j * kTS
+  constexpr int kTS = KS ? 1 : 4;
+  const int kh = KS ? wave >> 1 : 0;                                   // KS: which half of the steps
+  const bool idle = KS && kh;                                          // KS: no start values, no epilogue
 
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, K * a.Cin * a.Mpad * 4, kRsrcFlags);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? M * 4 : 0, kRsrcFlags);
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
   constexpr int kPF = 4;
   float pfv[kPF];
   {
-    const int lpr = 16 * NRT;                                          // 128-byte lines per (tap, group, h) run of a row block
+    const int lpr = kRowsBlk / 8;                                      // 128-byte lines per (tap, group, h) run of a row block
     const int n_lines = K * G * 2 * lpr;
     const int first_rb = blockIdx.x % gm.n_rblk;
     const int jj = blockIdx.x / gm.pf_period;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
     for (int i = 0; i < kPF; ++i) {
       const int idx = (jj + i * n_same) * 256 + tid;
       const int run = idx / lpr, within = idx - run * lpr;
-      const unsigned vo = idx < n_lines ? (unsigned)((run * a.Mpad + first_rb * 128 * NRT) * 16 + within * 128) : kOob;
+      const unsigned vo = idx < n_lines ? (unsigned)((run * a.Mpad + first_rb * kRowsBlk) * 16 + within * 128) : kOob;
       pfv[i] = bload1(w_rs, vo, 0);
     }
   }
@@ -136,8 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
     const int b = half ? hb[1] : hb[0];
     const int t = (half ? ht0[1] : ht0[0]) + jl;                       // this lane's output frame
     const bool tv = (half ? hok[1] : hok[0]) && t < T;
-    const int row_blk0 = rb * (128 * NRT);
-    const unsigned w_voff = (unsigned)((hl * a.Mpad + row_blk0 + wave * 32 + l31) * 16);
+    const int row_blk0 = rb * kRowsBlk;
+    const unsigned w_voff = (unsigned)((hl * a.Mpad + row_blk0 + tile0 * 32 + l31) * 16);
+    // first row of the wave's j-th tile as the start values / epilogue see it: past M for a wave without an
+    // epilogue, so that every `row0 < M` test below skips it (and its bias loads read zeros)
+#define MBV_ROW0(J) (idle ? M + 32 : row_blk0 + (tile0 + (J) * kTS) * 32)
     const unsigned y_voff = tv ? (unsigned)(b * (int)a.y_bstride + 4 * hl * T + t) * 4u : kOob;
     const int xoff = half * gm.XS + jl;
 
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       const unsigned rc_voff = (unsigned)(b * M + 4 * hl) * 4u;
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
-        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        const int row0 = MBV_ROW0(j);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v = bload4(b_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);  // past M / no bias: reads 0
@@ -197,11 +210,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       const unsigned dWt = (unsigned)G * w_step, dWw = w_step - (unsigned)K * dWt;   // (the wrap comes on top of a tap step)
       unsigned so = (unsigned)g0 * w_step;
       int ltap = 0;
-#define MBV_ADV_W() { so += dWt; if (++ltap == K) { ltap = 0; so += dWw; } }
+#define MBV_ADV_W1() { so += dWt; if (++ltap == K) { ltap = 0; so += dWw; } }
+#define MBV_ADV_W() { MBV_ADV_W1() if constexpr (KS) MBV_ADV_W1() }    /* KS: a wave takes every second step */
+      if (KS && kh) MBV_ADV_W1()
 #pragma unroll
       for (int d = 0; d < kD - 1; ++d) {
 #pragma unroll
-        for (int j = 0; j < NRT; ++j) ra[d][j] = bload4(w_rs, w_voff, so + j * 2048u);
+        for (int j = 0; j < NRT; ++j) ra[d][j] = bload4(w_rs, w_voff, so + j * kJS);
         MBV_ADV_W()
       }
       __syncthreads();                                                 // the previous block's / unit's readers of Xs are done
@@ -258,14 +273,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         const f32x4* xl = Xs + hl * XL + xoff;
         const int dXw = 2 * XL - K * a.dil, xo_max = (GB - 1) * 2 * XL + (K - 1) * a.dil;
         int xo = 0, ntap = 0;             // window offset of the step after the one being multiplied
-#define MBV_ADV_X() { xo += a.dil; if (++ntap == K) { ntap = 0; xo += dXw; } }
+#define MBV_ADV_X1() { xo += a.dil; if (++ntap == K) { ntap = 0; xo += dXw; } }
+#define MBV_ADV_X() { MBV_ADV_X1() if constexpr (KS) MBV_ADV_X1() }
+        if (KS && kh) MBV_ADV_X1()
         f32x4 bvv[2];
-        bvv[0] = xl[0];
+        bvv[0] = xl[xo];
         MBV_ADV_X()
-        for (int s0 = 0; s0 < steps_blk; s0 += kD) {
+        const int my_steps = KS ? steps_blk / 2 : steps_blk;           // (KS: the host makes steps_blk even)
+        for (int s0 = 0; s0 < my_steps; s0 += kD) {
 #pragma unroll
           for (int d = 0; d < kD; ++d) {
-            if (s0 + d < steps_blk) {
+            if (s0 + d < my_steps) {
               // One step = 4 K-steps x NRT row tiles.  The bookkeeping (next ring load, next window read,
               // cursor arithmetic) is issued BETWEEN the MFMAs: a wave stalls at every MFMA until the pipe
               // takes it, so scalar work placed there is free, while in front of the first MFMA of a step it
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
 #if defined(MBV_NARROW_STAMPS) && MBV_NARROW_EXP == 1      // timeline experiment: no weight loads inside the loop
                 asm volatile("" : "+v"(ra[(d + kD - 1) % kD][j]) : "s"(so));
 #else
-                ra[(d + kD - 1) % kD][j] = bload4(w_rs, w_voff, so + j * 2048u);
+                ra[(d + kD - 1) % kD][j] = bload4(w_rs, w_voff, so + j * kJS);
 #endif
               }
               MBV_ADV_W()
@@ -304,7 +322,27 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
           }
         }
 #undef MBV_ADV_X
+#undef MBV_ADV_X1
 #undef MBV_ADV_W
+#undef MBV_ADV_W1
+      }
+    }
+    if constexpr (KS) {
+      // waves 2 / 3 hand their halves over: [pair][tile][register][lane], lane-contiguous
+      __syncthreads();                                                 // every wave is done with the input window
+      float* const xch = lds + (size_t)((wave & 1) * NRT) * 16 * 64 + lane;
+      if (kh) {
+#pragma unroll
+        for (int j = 0; j < NRT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64] = acc[j][r];
+      }
+      __syncthreads();
+      if (!kh) {
+#pragma unroll
+        for (int j = 0; j < NRT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += xch[(j * 16 + r) * 64];
       }
     }
 
@@ -320,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       float part = 0.f;
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
-        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        const int row0 = MBV_ROW0(j);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k = (r & 3) + 8 * (r >> 2);
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       float sq = 0.f;
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
-        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        const int row0 = MBV_ROW0(j);
         if (row0 < M) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { const float d = acc[j][r] - mean; sq += d * d; }
@@ -359,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       const unsigned bvo = (unsigned)(4 * hl) * 4u;
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
-        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        const int row0 = MBV_ROW0(j);
         if (row0 >= M) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       const bool keep = !a.out_lens || t < a.out_lens[b];
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
-        const int row0 = row_blk0 + (wave + 4 * j) * 32;
+        const int row0 = MBV_ROW0(j);
         if (row0 >= M) continue;                                       // idle tile slot (rows past M would land in the next utterance)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -394,32 +432,34 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       }
     }
     MBV_STAMP(5)
+#undef MBV_ROW0
   }
 #pragma unroll
   for (int i = 0; i < kPF; ++i) asm volatile("" ::"v"(pfv[i]));
 }
 
-template <int NRT, int EPI>
+template <int NRT, int EPI, bool KS = false>
 void launch_narrow_t(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
-  const size_t lds_bytes = (size_t)(gm.CB / 8) * 2 * 2 * gm.XS * 16;
+  size_t lds_bytes = (size_t)(gm.CB / 8) * 2 * 2 * gm.XS * 16;
+  if (KS && lds_bytes < (size_t)2 * NRT * 16 * 64 * 4) lds_bytes = (size_t)2 * NRT * 16 * 64 * 4;   // the pairs' hand-over
   const long units = (long)gm.n_ctiles * gm.n_rblk;
   const int grid = (int)(units < 512 ? (units < 1 ? 1 : units) : 512);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_narrow_kernel<NRT, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_narrow_kernel<NRT, EPI, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((conv1d_narrow_kernel<NRT, EPI>), dim3(grid), dim3(256), lds_bytes, s, a, gm);
+  hipLaunchKernelGGL((conv1d_narrow_kernel<NRT, EPI, KS>), dim3(grid), dim3(256), lds_bytes, s, a, gm);
 }
 
-template <int NRT>
+template <int NRT, bool KS = false>
 void launch_narrow_epi(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
   switch (a.epi) {
-    case EPI_STORE: launch_narrow_t<NRT, EPI_STORE>(a, gm, s); break;
-    case EPI_RESID: launch_narrow_t<NRT, EPI_RESID>(a, gm, s); break;
-    case EPI_LN: launch_narrow_t<NRT, EPI_LN>(a, gm, s); break;
-    default: launch_narrow_t<NRT, EPI_RESID_ACC>(a, gm, s); break;
+    case EPI_STORE: launch_narrow_t<NRT, EPI_STORE, KS>(a, gm, s); break;
+    case EPI_RESID: launch_narrow_t<NRT, EPI_RESID, KS>(a, gm, s); break;
+    case EPI_LN: launch_narrow_t<NRT, EPI_LN, KS>(a, gm, s); break;
+    default: launch_narrow_t<NRT, EPI_RESID_ACC, KS>(a, gm, s); break;
   }
 }
 
@@ -461,6 +501,21 @@ void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s)
   int nrt = (tiles_m + 3) / 4;
   if (nrt > 6) nrt = 6;
   while (by_launch_size && nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
+  // six row tiles (192 channels: the text encoder's conv_o and conv_2) do not divide over four waves: K-split
+  // wave pairs of three tiles each (a rule on M alone).  The pairs alternate steps, so a block has an even number.
+  static const int ks_env = [] { const char* e = getenv("MBV_NARROW_KS"); return e ? atoi(e) : 1; }();
+  const bool ks = ks_env && !by_launch_size && tiles_m == 6 && a.M == 192;
+  if (ks) {
+    int cbk = cb;                                                    // largest block that divides Cin with an even step count
+    while (cbk >= 8 && (a.Cin % cbk || ((cbk / 8) * a.K) % 2)) cbk -= 8;
+    if (cbk >= 8) {
+      gm.CB = cbk;
+      gm.n_rblk = 1;
+      gm.pf_period = 8;
+      launch_narrow_epi<3, true>(a, gm, s);
+      return;
+    }
+  }
   gm.n_rblk = (tiles_m + 4 * nrt - 1) / (4 * nrt);
   gm.pf_period = 8;
   while (gm.pf_period % gm.n_rblk) gm.pf_period += 8;               // lcm(8, n_rblk)

@@ -14,19 +14,21 @@ static size_t pack_idx(int tap, int ci, int m, int Cin, int Mpad) {
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 128, K = argc > 2 ? atoi(argv[2]) : 7, T = argc > 3 ? atoi(argv[3]) : 4240;
   const int B = argc > 4 ? atoi(argv[4]) : 1, iters = 20;
+  const bool by_size = argc > 5 ? atoi(argv[5]) != 0 : true;      // 0: the default mode's geometry (rules on M / T only)
+  const int Cin = argc > 6 ? atoi(argv[6]) : C;
   const int Mpad = (C + 127) / 128 * 128;
   std::mt19937 rng(1); std::normal_distribution<float> nd(0.f, 1.f);
-  std::vector<float> W((size_t)C * C * K), bias(C), x((size_t)B * C * T), wp((size_t)K * C * Mpad, 0.f);
-  for (auto& v : W) v = nd(rng) / std::sqrt((float)C * K);
+  std::vector<float> W((size_t)C * Cin * K), bias(C), x((size_t)B * Cin * T), wp((size_t)K * Cin * Mpad, 0.f), yv((size_t)B * C * T);
+  for (auto& v : W) v = nd(rng) / std::sqrt((float)Cin * K);
   for (auto& v : bias) v = nd(rng) * 0.1f;
   for (auto& v : x) v = nd(rng);
-  for (int m = 0; m < C; ++m) for (int ci = 0; ci < C; ++ci) for (int k = 0; k < K; ++k) wp[pack_idx(k, ci, m, C, Mpad)] = W[((size_t)m * C + ci) * K + k];
+  for (int m = 0; m < C; ++m) for (int ci = 0; ci < Cin; ++ci) for (int k = 0; k < K; ++k) wp[pack_idx(k, ci, m, Cin, Mpad)] = W[((size_t)m * Cin + ci) * K + k];
   float *d_x, *d_y, *d_w, *d_b, *d_ws;
-  hipMalloc(&d_x, x.size() * 4); hipMalloc(&d_y, x.size() * 4); hipMalloc(&d_w, wp.size() * 4); hipMalloc(&d_b, C * 4); hipMalloc(&d_ws, 512 * 8 * 8);
+  hipMalloc(&d_x, x.size() * 4); hipMalloc(&d_y, yv.size() * 4); hipMalloc(&d_w, wp.size() * 4); hipMalloc(&d_b, C * 4); hipMalloc(&d_ws, 512 * 8 * 8);
   hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_b, bias.data(), C * 4, hipMemcpyHostToDevice); hipMemset(d_ws, 0, 512 * 64);
   ConvArgs a{};
-  a.x = d_x; a.x_bstride = (int64_t)C * T; a.Tin = T; a.x_rstride = T; a.Cin = C; a.w = d_w; a.bias = d_b; a.M = C; a.Mpad = Mpad; a.K = K; a.dil = 1;
+  a.x = d_x; a.x_bstride = (int64_t)Cin * T; a.Tin = T; a.x_rstride = T; a.Cin = Cin; a.w = d_w; a.bias = d_b; a.M = C; a.Mpad = Mpad; a.K = K; a.dil = 1;
   a.pad_left = (K - 1) / 2; a.in_slope = 0.1f; a.y = d_y; a.y_bstride = (int64_t)C * T; a.T = T; a.epi = EPI_STORE; a.B = B; a.ws = d_ws; a.out_scale = 1.f;
   if (!conv1d_narrow_supported(a)) { printf("not supported\n"); return 1; }
   // a scratch kernel between launches so that every timed launch starts from the state a pipeline leaves (x rewritten by another kernel)
@@ -35,13 +37,13 @@ int main(int argc, char** argv) {
   for (int it = 0; it < iters; ++it) {
     hipMemcpyAsync(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice, 0);   // x arrives from elsewhere, as in the pipeline
     hipEventRecord(e0, 0);
-    launch_conv1d_narrow(a, true, 0);
+    launch_conv1d_narrow(a, by_size, 0);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms[it], e0, e1);
   }
   std::sort(ms.begin(), ms.end());
-  printf("C=%d K=%d T=%d B=%d: launch median %.1f us (min %.1f)\n", C, K, T, B, ms[iters / 2] * 1e3, ms[0] * 1e3);
+  printf("M=%d K=%d T=%d B=%d: launch median %.1f us (min %.1f)\n", C, K, T, B, ms[iters / 2] * 1e3, ms[0] * 1e3);
   std::vector<unsigned long long> st(512 * 8);
   hipMemcpy(st.data(), d_ws, 512 * 64, hipMemcpyDeviceToHost);
   unsigned long long t0 = ~0ull; int nb = 0;
@@ -54,12 +56,12 @@ int main(int argc, char** argv) {
          (double)(st[7] - st[6]) / ((st[4] - st[3]) * 10.0));
   for (int b : {0, 1, 8, 64, nb - 1}) { printf("wg %3d", b); for (int i = 0; i < 6; ++i) printf(" %7.2f", (st[b * 8 + i] - t0) * 0.01); printf("\n"); }
   // parity
-  std::vector<float> y(x.size());
+  std::vector<float>& y = yv;
   hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost);
   double err = 0;
   for (int m = 0; m < C; m += 17) for (int t = 0; t < T; t += 97) {
     double v = bias[m];
-    for (int ci = 0; ci < C; ++ci) for (int k = 0; k < K; ++k) { const int ti = t + k - (K - 1) / 2; if (ti >= 0 && ti < T) { float xv = x[(size_t)ci * T + ti]; xv = xv > 0 ? xv : 0.1f * xv; v += (double)W[((size_t)m * C + ci) * K + k] * xv; } }
+    for (int ci = 0; ci < Cin; ++ci) for (int k = 0; k < K; ++k) { const int ti = t + k - (K - 1) / 2; if (ti >= 0 && ti < T) { float xv = x[(size_t)ci * T + ti]; xv = xv > 0 ? xv : 0.1f * xv; v += (double)W[((size_t)m * Cin + ci) * K + k] * xv; } }
     err = std::max(err, std::fabs(v - y[(size_t)m * T + t]));
   }
   printf("max |err| vs CPU loop (utterance 0, sampled): %.2e %s\n", err, err < 1e-4 ? "OK" : "MISMATCH");
