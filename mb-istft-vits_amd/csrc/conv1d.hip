@@ -858,11 +858,13 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
     }
     if (narrow && conv1d_narrow_supported(a)) {
       const long tiles128 = (long)((a.T + 127) / 128) * ((a.M + 127) / 128) * a.B;
-      // (a handful of column tiles — the text encoder of one short utterance — is better served by
-      // split-K over the long Cin loop than by 8 workgroups walking it alone)
+      // (fewer than 16 units — conv_o / conv_2 of the text encoder of one short utterance: 8 — are better
+      // served by split-K over the long Cin loop than by 8 workgroups walking it alone; measured on ljs_mb,
+      // one utterance: threshold 48 / 16 / 4 -> 4.43 / 4.15 / 4.34 ms per infer)
       const long units32 = (((long)a.B * ((a.T + 15) / 16) + 1) / 2) * ((a.M + 127) / 128);
       if (a.splitk && tiles128 <= 128) {
-        if (units32 >= 48 || narrow == 2) { launch_conv1d_narrow(a, true, s); return; }
+        static const int min_units = [] { const char* e = getenv("MBV_NARROW_MIN_UNITS"); return e ? atoi(e) : 16; }();
+        if (units32 >= min_units || narrow == 2) { launch_conv1d_narrow(a, true, s); return; }
       } else if (a.T <= 256 || narrow == 2) {
         launch_conv1d_narrow(a, false, s);
         return;
