@@ -12,13 +12,20 @@
 //     block of 128 NRT rows; row blocks of one column tile are separate workgroups (no reduction:
 //     rows are independent), so a 128-channel conv on 4 240 frames is 133 workgroups of 4 x 1 tile;
 //   * the A operand comes straight from L2 (a lane's four K-steps = one 16-byte load of the packed
-//     weights conv1d.hip uses too), through a register ring three steps ahead; the input window (all
-//     channels of a block of CB channels x 2 x (16 + halo) frames, activation / mask / conditioning
-//     applied on the way in) is the only thing staged in LDS; two barriers per channel block.
-// (Measured and dropped, r02: two column tiles per workgroup with the rows over two waves each, for
-// heights of 6 row tiles that four waves split 2 / 2 / 1 / 1 — the better balance is paid for with half
-// as many workgroups: text encoder 3.03 -> 2.99 ms at batch 64 but 2.15 -> 2.53 ms at batch 32.)
-// Epilogues: STORE (+ relu, + output mask), RESID, RESID_ACC — what the text encoder and the
+//     weights conv1d.hip uses too), through a register ring 11 / 7 / 3 steps ahead (1 / 2 / >= 3 row tiles
+//     per wave), after a prologue in which the workgroups of an XCD touch their row block's weight lines
+//     once; the input window (all channels of a block of CB channels x 2 x (16 + halo) frames, activation /
+//     mask / conditioning applied on the way in) is the only thing staged in LDS; two barriers per channel
+//     block;
+//   * a step (one tap of one 8-channel group = 4 K-steps) is 4 NRT MFMAs and a handful of scalar additions:
+//     the cursors advance additively and the bookkeeping sits between the MFMAs (see the kernel);
+//   * 192-row outputs use K-split wave pairs (template parameter KS).
+// (Measured and dropped, r02: two column tiles per workgroup with the rows over two waves each — text
+// encoder 3.03 -> 2.99 ms at batch 64 but 2.15 -> 2.53 ms at batch 32; the next block's window requested
+// before the MFMA loop of the current one into a second LDS buffer: 2.78 -> 2.75 ms at batch 64, slower
+// for a single utterance.)
+// Epilogues: STORE (+ relu, + output mask), RESID, RESID_ACC, LN (conv -> (relu) -> + residual -> channel
+// LayerNorm, one row block holding every channel) — what the text encoder, the duration predictor and the
 // decoder's ResBlocks need; everything else stays on conv1d.hip.
 #include "kernels.h"
 #include <cstdio>
