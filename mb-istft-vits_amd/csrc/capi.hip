@@ -108,6 +108,7 @@ struct mbv_model {
   hipEvent_t ev_fork{}, ev_rb[3]{};
   bool aux_ok = false;
   int dec_streams = 1;          // option "dec_streams" / MBV_DEC_STREAMS: 0 = always one stream
+  int conv_bf16 = 0;            // option "conv_bf16" / MBV_CONV_BF16: 3 = opt-in split-bf16 arithmetic in the large conv launches
   bool ev_ok = false, ev_a = false, ev_b = false, evk_set = false;
 
   int fail(const char* fmt, ...) {
@@ -792,6 +793,7 @@ ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x
   a.y = y; a.y_bstride = y_bstride; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   a.splitk = m->splitk;
+  a.prec = m->conv_bf16;
   return a;
 }
 
@@ -1154,6 +1156,7 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   m->ev_ok = true;
   { const char* e = getenv("MBV_DEC_STREAMS"); m->dec_streams = e ? (atoi(e) != 0) : 1; }
+  { const char* e = getenv("MBV_CONV_BF16"); m->conv_bf16 = (e && atoi(e) == 3) ? 3 : 0; }
   {
     bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (auto& e : m->ev_rb) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -1186,7 +1189,12 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!strcmp(name, "wn_fused")) { m->wn_fused = value != 0; return 0; }
   if (!strcmp(name, "xpost_chunk_bytes")) { m->xpost_chunk_bytes = value > 0 ? value : 0; return 0; }
   if (!strcmp(name, "dec_streams")) { m->dec_streams = value != 0; return 0; }
-  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams)", name);
+  if (!strcmp(name, "conv_bf16")) {
+    if (value != 0 && value != 3) return m->fail("mbv_set_option: conv_bf16 takes 0 (exact fp32) or 3 (split-bf16, three products)");
+    m->conv_bf16 = value;
+    return 0;
+  }
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams, conv_bf16)", name);
 }
 
 void mbv_destroy(mbv_model* m) {
@@ -1744,6 +1752,7 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   a.y = y; a.y_bstride = (int64_t)Cout * T; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   a.splitk = m->splitk;
+  a.prec = m->conv_bf16;
   launch_conv1d(a, s);
   HIPCHK(m, hipStreamSynchronize(s));
   HIPCHK(m, hipFree(dw));

@@ -50,6 +50,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// Opt-in split-bf16 arithmetic (ConvArgs::prec == 3, mbv_set_option "conv_bf16"): x = hi + mid + O(2^-17 x)
+// with hi = bf16(x), mid = bf16(x - hi); a product keeps hi*hi + hi*mid + mid*hi (relative error ~2^-16),
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16 — 3 MFMAs of 32 cycles per 16 K-values instead of 8 of
+// 64.  The operands are split in registers on their way from the SAME fp32 LDS images the exact path
+// reads: eight K-values of a lane = two of its 16-byte reads (two steps).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_bf16(const f32x4& r0, const f32x4& r1, bf16x8& hi, bf16x8& mid) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float v = k < 4 ? r0[k] : r1[k - 4];
+    const __bf16 h = (__bf16)v;
+    hi[k] = h;
+    mid[k] = (__bf16)(v - (float)h);
+  }
+}
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // Start values of a wave's accumulators: everything the epilogue would otherwise have to READ
@@ -166,7 +182,7 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
 // with one workgroup per CU it used to run with the matrix pipe idle: measured 25 % of a k=3 conv)
 // is then followed immediately by MFMA work on data already in LDS, so its stores drain underneath.
 // No staging registers are live across the epilogue.
-template <int WM, int WN, int CK, int NWN, int EPI>
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0>
 __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
                                                                    int tiles_y, int total_tiles,
                                                                    int ksplit) {
@@ -502,7 +518,47 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
             // staged as zeros and never stored, so the few MFMAs they cost on the last tile of a row
             // buy a loop without exec-mask juggling around every MFMA
             static_assert(NWN == 4, "");
-            if (nj > 0) MBV_STEP_LOOP(true)
+            if constexpr (PREC == 3) {
+              // split-bf16: two steps (16 K-values per lane half) per MFMA; no operand double-buffering (the
+              // registers go to the split planes), the other wave of the SIMD covers the LDS latency
+              if (nj > 0) {
+                for (int st = 0; st < nsteps; st += 2) {
+                  f32x4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];
+                  MBV_LOAD_AB(st, ra0, rb0);
+                  if (st + 1 < nsteps) {
+                    MBV_LOAD_AB(st + 1, ra1, rb1);
+                  } else {                                   // odd step count: the second half of the K-values is absent
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) ra1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) rb1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                  }
+                  bf16x8 ah[WM], am[WM], bh[WN], bm[WN];
+#pragma unroll
+                  for (int i = 0; i < WM; ++i) split_bf16(ra0[i], ra1[i], ah[i], am[i]);
+#pragma unroll
+                  for (int j = 0; j < WN; ++j) split_bf16(rb0[j], rb1[j], bh[j], bm[j]);
+                  // three rounds over the six accumulators: consecutive MFMAs never share one
+#pragma unroll
+                  for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                  for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                  for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+              }
+            } else {
+              if (nj > 0) MBV_STEP_LOOP(true)
+            }
           }
 #undef MBV_STEP_LOOP
 #undef MBV_LOAD_AB
@@ -748,7 +804,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 #undef MBV_GLDS_DRAIN
 }
 
-template <int WM, int WN, int CK, int NWN, int EPI>
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0>
 static void launch_epi(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = 64 * WM, BN = 32 * WN * NWN, G = CK / 8;
   const int XL = BN + (a.K - 1) * a.dil;
@@ -791,11 +847,11 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   a2.debug = dbg;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the split-K ticket
     attr = true;
   }
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,
                      tiles_x, tiles_y, (int)total, S);
 }
 
@@ -804,6 +860,18 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
 // SGPRs spilled to VGPR lanes) and a k=3 conv spent a quarter of its time walking that code.
 template <int WM, int WN, int CK, int NWN>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
+  // opt-in split-bf16 (ConvArgs::prec): built for the 128 x 384 shape and the epilogues of the decoder's
+  // ResBlock convs, where the time is; everything else stays exact fp32
+  if constexpr (NWN == 4 && WM == 2 && WN == 3 && CK <= 16) {
+    if (a.prec == 3) {
+      switch (a.epi) {
+        case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE, 3>(a, s); return;
+        case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID, 3>(a, s); return;
+        case EPI_RESID_ACC: launch_epi<WM, WN, CK, NWN, EPI_RESID_ACC, 3>(a, s); return;
+        default: break;
+      }
+    }
+  }
   switch (a.epi) {
     case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE>(a, s); break;
     case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID>(a, s); break;

@@ -73,6 +73,7 @@ struct ConvArgs {
   int n_counters;
   int convt_u;             // EPI_CONVT: upsampling stride (4 or 8)
   int splitk;              // 1: split-K allowed for this launch (mbv_set_option "splitk" / MBV_CONV_SPLITK)
+  int prec;                // 0: exact fp32 MFMA (default); 3: opt-in split-bf16, three products (mbv_set_option "conv_bf16")
   // EPI_LN
   const float* ln_gamma;   // [M]
   const float* ln_beta;    // [M]

@@ -499,7 +499,8 @@ class SynthesizerTrn(nn.Module):
 
     def set_option(self, name, value):
         """Run-time options of the library (`mbv_set_option`): "splitk" (low-latency split-K for
-        small launches), "istft_exact", "xpost_chunk_bytes", "wn_fused", "dec_streams".  Kept across weight refreshes; a
+        small launches), "istft_exact", "xpost_chunk_bytes", "wn_fused", "dec_streams", "conv_bf16" (0 / 3: opt-in split-bf16
+        arithmetic in the large conv launches, see include/mbistft_vits.h).  Kept across weight refreshes; a
         handle re-created on another device starts from the defaults again."""
         h = self._ensure_handle()
         _capi.check(h, _capi.lib().mbv_set_option(h, name.encode(), int(value)), "mbv_set_option")

@@ -364,6 +364,33 @@ def test_oversized_batch_is_split_not_refused():
     assert _same_rows(o_s, o[rows]) and _same_rows(spec_s, spec[rows])
 
 
+def test_split_bf16_mode_meets_the_waveform_bar():
+    """Opt-in `conv_bf16 = 3` at BASELINE configs[1] size (the large decoder convs run on the bf16 MFMA with
+    split operands): deterministic, waveform within the north-star bar (1e-4 RMS) of the oracle on two
+    utterances at the padded T', durations untouched (the text encoder never takes the mode)."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits")
+    B = 64
+    x, xl, sid = synth.synthetic_batch(net.cfg, B, 200, seed=0)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    exact, ylen0 = net.infer_with_lengths(xg, xlg, None, noise_scale=0, length_scale=1)
+    net.set_option("conv_bf16", 3)
+    try:
+        r, ylen = net.infer_with_lengths(xg, xlg, None, noise_scale=0, length_scale=1)
+        r2 = net.infer(xg, xlg, None, noise_scale=0, length_scale=1)
+    finally:
+        net.set_option("conv_bf16", 0)
+    o, Tp = r[0], r[6][0].shape[-1]
+    assert torch.equal(o, r2[0]) and torch.equal(ylen, ylen0)
+    assert not torch.equal(o, exact[0])                                   # the mode was taken
+    assert rms((o - exact[0]).cpu().numpy()) < 2e-5
+    torch.set_num_threads(8)
+    pick = [5, B - 3]
+    ref = R.infer(sd, net.cfg, x[pick], xl[pick], None, t_frames=Tp)
+    assert rms(o[pick].cpu().numpy() - ref["o"].numpy()) < 1e-4
+
+
 def test_resblock_streams_are_bitwise_the_one_stream_schedule():
     """Small launches run the three ResBlocks of a decoder stage on three streams (capi.hip run_decoder):
     same kernels, the running-sum updates chained in the one-stream order, so every output must be

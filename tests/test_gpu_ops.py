@@ -54,6 +54,40 @@ def test_conv1d_mfma(net, B, Cin, Cout, T, K, dil, slope):
     assert err <= 2e-5 * rms(ref.numpy()) + 1e-7, err
 
 
+@pytest.mark.parametrize("Cin,Cout,T,K,dil", [(128, 128, 3072, 7, 3), (128, 128, 3100, 11, 5), (256, 256, 1536, 3, 1),
+                                             (128, 128, 3072, 3, 5), (128, 72, 3001, 7, 1)])
+def test_conv1d_split_bf16_mode(Cin, Cout, T, K, dil):
+    """Opt-in `conv_bf16 = 3` (hi/mid bf16 planes, three products, fp32 accumulation on the bf16 MFMA) in the
+    128 x 384 conv kernel: launches large enough to take that shape (>= 512 tiles), against torch's fp32
+    conv on the GPU.  Bar for this mode: 3e-5 of the output RMS per conv (measured ~5e-6; the exact path's
+    bar is 2e-5 with ~3e-7 measured) — and the mode must actually be taken (the result differs from the
+    exact path's) and must leave the default untouched."""
+    from gpu_util import make_net, op_conv1d
+    net = make_net("ljs_mini_mb_istft_vits")[0]
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(Cin + T + K)
+    x = torch.randn(B, Cin, T, device="cuda", generator=g)
+    rs = np.random.RandomState(K * 100 + dil)
+    w = (rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    ref = F.conv1d(F.leaky_relu(x, 0.1), torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda(),
+                   padding=(K - 1) * dil // 2, dilation=dil)
+    scale = float(ref.pow(2).mean().sqrt())
+    exact = op_conv1d(net, x, w, b, K, dil, 0.1)
+    net.set_option("conv_bf16", 3)
+    try:
+        split = op_conv1d(net, x, w, b, K, dil, 0.1)
+        split2 = op_conv1d(net, x, w, b, K, dil, 0.1)
+    finally:
+        net.set_option("conv_bf16", 0)
+    again = op_conv1d(net, x, w, b, K, dil, 0.1)
+    e_exact = float((exact - ref).pow(2).mean().sqrt()) / scale
+    e_split = float((split - ref).pow(2).mean().sqrt()) / scale
+    assert e_exact < 2e-5 and e_split < 3e-5, (e_exact, e_split)
+    assert torch.equal(split, split2) and torch.equal(exact, again)
+    assert not torch.equal(split, exact)
+
+
 def test_istft_pqmf_known_answers(net):
     """Stand-alone kernel vs the reference's TorchSTFT.inverse / PQMF.synthesis vectors:
     x_post is built so that exp()/pi*sin() reproduce the stored mag/phase."""
