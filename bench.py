@@ -241,6 +241,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wave_elapsed = float(t.item())
 
+    # tertiary: the OPT-IN split-bf16 conv mode (conv_bf16 = 3; not IEEE fp32 multiplication, so never the
+    # headline): same job, all outputs, plus its waveform's distance from the exact mode's
+    o_exact = o.clone()
+    net.set_option("conv_bf16", 3)
+    try:
+        for _ in range(2):
+            o3, _ = step()
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(n_wave):
+            o3, _ = step()
+        sync()
+        bf16_elapsed = time.perf_counter() - t2
+        bf16_rms = float((o3.double() - o_exact.double()).pow(2).mean().sqrt())
+    finally:
+        net.set_option("conv_bf16", 0)
+    if dist_on:
+        t = torch.tensor([bf16_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bf16_elapsed = float(t.item())
+
     dist_info = None
     if dist_on:
         names = [None] * world
@@ -383,6 +404,11 @@ def main():
             "waveform_only": {"what": "same job with infer(outputs=('o',)) (a caller that takes [0] only)",
                               "value": round(valid_samples * n_wave / wave_elapsed, 1),
                               "ms_per_step": round(wave_elapsed / n_wave * 1e3, 3)},
+            "conv_bf16": {"what": "OPT-IN mode mbv_set_option('conv_bf16', 3): split-bf16 operands (hi + mid planes, three products, "
+                                  "fp32 accumulation) in the large conv launches; all 8 outputs; NOT the headline (the headline is exact fp32)",
+                          "value": round(valid_samples * n_wave / bf16_elapsed, 1),
+                          "ms_per_step": round(bf16_elapsed / n_wave * 1e3, 3),
+                          "waveform_rms_vs_exact_mode": bf16_rms, "bar": 1e-4},
             "dist": dist_info,
             "stage_ms": stage_ms, "roofline": roof, "roofline_conv": roof_conv, "roofline_other": roof_other,
             "cpu_baseline": cpu,

@@ -56,6 +56,9 @@ struct mbv_model {
   std::vector<float> harena;
   float* darena = nullptr;
   size_t darena_floats = 0;
+  float* darena_split = nullptr;   // conv_bf16 mode: the arena as [bf16 hi x 4 | bf16 mid x 4] slots (ensure_split_arena)
+  size_t darena_split_floats = 0;
+  bool split_valid = false;
 
   // packed weights
   struct Layer { PConv qkv, o, ffn1, ffn2; PVec ek, ev, g1, b1, g2, b2; };
@@ -118,6 +121,7 @@ struct mbv_model {
     return 1;
   }
   const float* W(size_t off) const { return darena + off; }
+  const float* Wsplit(size_t off) const { return (conv_bf16 == 3 && split_valid) ? darena_split + off : nullptr; }
 };
 
 #define HIPCHK(m, call)                                                              \
@@ -127,6 +131,24 @@ struct mbv_model {
   } while (0)
 
 namespace {
+
+// conv_bf16 mode: (re)build the split copy of the weight arena (ops.hip launch_split_planes)
+int ensure_split_arena(mbv_model* m, hipStream_t stream) {
+  if (m->split_valid) return 0;
+  if (!m->darena) return m->fail("conv_bf16: no weights on the device yet");
+  if (m->darena_split && m->darena_split_floats < m->darena_floats) {
+    HIPCHK(m, hipFree(m->darena_split));
+    m->darena_split = nullptr;
+  }
+  if (!m->darena_split) {
+    HIPCHK(m, hipMalloc((void**)&m->darena_split, m->darena_floats * sizeof(float)));
+    m->darena_split_floats = m->darena_floats;
+  }
+  launch_split_planes(m->darena, m->darena_split, m->darena_floats, stream);
+  HIPCHK(m, hipStreamSynchronize(stream));
+  m->split_valid = true;
+  return 0;
+}
 
 // Every entry point runs on the model's device and hands the caller's current device back on
 // every exit path (a process may host models on several GPUs; hipSetDevice is per host thread).
@@ -759,6 +781,8 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
   HIPCHK(m, hipStreamSynchronize(stream));
   m->harena.swap(arena);
   m->finalized = true;
+  m->split_valid = false;
+  if (m->conv_bf16 == 3 && ensure_split_arena(m, stream)) return 1;
   return 0;
 }
 
@@ -787,13 +811,14 @@ ConvArgs conv_args(const mbv_model* m, const PConv& p, const float* x, int64_t x
   ConvArgs a{};
   a.x = x; a.x_bstride = x_bstride; a.Tin = Tin; a.x_rstride = Tin; a.Cin = p.Cin;
   a.w = m->W(p.w); a.bias = p.has_bias ? m->W(p.bias) : nullptr;
+  a.w_split = m->Wsplit(p.w);
   a.M = p.M; a.Mpad = p.Mpad; a.K = p.K; a.dil = dil;
   a.pad_left = (p.K - 1) * dil / 2;
   a.in_slope = 1.f;
   a.y = y; a.y_bstride = y_bstride; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   a.splitk = m->splitk;
-  a.prec = m->conv_bf16;
+  a.prec = a.w_split ? 3 : 0;
   return a;
 }
 
@@ -1192,6 +1217,7 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!strcmp(name, "conv_bf16")) {
     if (value != 0 && value != 3) return m->fail("mbv_set_option: conv_bf16 takes 0 (exact fp32) or 3 (split-bf16, three products)");
     m->conv_bf16 = value;
+    if (value == 3 && m->finalized && ensure_split_arena(m, nullptr)) return 1;
     return 0;
   }
   return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams, conv_bf16)", name);
@@ -1201,6 +1227,7 @@ void mbv_destroy(mbv_model* m) {
   if (!m) return;
   DeviceGuard dev_guard_(m->cfg.device);
   if (m->darena) (void)hipFree(m->darena);
+  if (m->darena_split) (void)hipFree(m->darena_split);
   if (m->conv_ws) (void)hipFree(m->conv_ws);
   if (m->conv_cnt) (void)hipFree(m->conv_cnt);
   if (m->scrA) (void)hipFree(m->scrA);
@@ -1752,10 +1779,17 @@ int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float
   a.y = y; a.y_bstride = (int64_t)Cout * T; a.T = T; a.epi = EPI_STORE; a.out_scale = 1.f; a.B = B;
   a.ws = m->conv_ws; a.ws_floats = m->conv_ws_floats; a.counters = m->conv_cnt; a.n_counters = m->conv_ncnt;
   a.splitk = m->splitk;
-  a.prec = m->conv_bf16;
+  float* dws = nullptr;
+  if (m->conv_bf16 == 3) {                           // the split copy of this call's weights
+    HIPCHK(m, hipMalloc((void**)&dws, packed.size() * 4));
+    launch_split_planes(dw, dws, packed.size(), s);
+    a.w_split = dws;
+  }
+  a.prec = a.w_split ? 3 : 0;
   launch_conv1d(a, s);
   HIPCHK(m, hipStreamSynchronize(s));
   HIPCHK(m, hipFree(dw));
+  if (dws) HIPCHK(m, hipFree(dws));
   if (db) HIPCHK(m, hipFree(db));
   return 0;
 }

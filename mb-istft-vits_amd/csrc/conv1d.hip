@@ -50,23 +50,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // Opt-in split-bf16 arithmetic (ConvArgs::prec == 3, mbv_set_option "conv_bf16"): x = hi + mid + O(2^-17 x)
 // with hi = bf16(x), mid = bf16(x - hi); a product keeps hi*hi + hi*mid + mid*hi (relative error ~2^-16),
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16 — 3 MFMAs of 32 cycles per 16 K-values instead of 8 of
-// 64.  The operands are split in registers on their way from the SAME fp32 LDS images the exact path
-// reads: eight K-values of a lane = two of its 16-byte reads (two steps).
+// 64.  The LDS images keep their shape: a 16-byte slot of four K-values holds [hi x 4 | mid x 4] instead of
+// four floats.  The weights arrive that way (ConvArgs::w_split, split once per checkpoint by
+// launch_split_planes), the input window is split when it is committed to LDS (once per element — it is
+// read 2 K times), and an MFMA operand (eight K-values of a lane) is the matching halves of two slots:
+// no arithmetic between the LDS read and the MFMA.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split_bf16(const f32x4& r0, const f32x4& r1, bf16x8& hi, bf16x8& mid) {
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 split_slot(const f32x4& v) {
+  bf16x4 hi, mid;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float v = k < 4 ? r0[k] : r1[k - 4];
-    const __bf16 h = (__bf16)v;
+  for (int k = 0; k < 4; ++k) {
+    const __bf16 h = (__bf16)v[k];
     hi[k] = h;
-    mid[k] = (__bf16)(v - (float)h);
+    mid[k] = (__bf16)(v[k] - (float)h);
   }
+  struct { bf16x4 h, m; } o{hi, mid};
+  return __builtin_bit_cast(f32x4, o);
 }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+// the hi (PLANE = 0) or mid (PLANE = 1) halves of the slots of two consecutive steps as one MFMA operand
+template <int PLANE>
+__device__ __forceinline__ bf16x8 plane_of(const f32x4& s0, const f32x4& s1) {
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  const f32x4_ o = {s0[2 * PLANE], s0[2 * PLANE + 1], s1[2 * PLANE], s1[2 * PLANE + 1]};
+  return __builtin_bit_cast(bf16x8, o);
+}
 
 // Start values of a wave's accumulators: everything the epilogue would otherwise have to READ
 // after the MFMA loop (residual, running ResBlock sum, the tensor a flow layer updates in place);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
     const int tile_ = (TILE);                                                                \
     const int tx_ = tile_ % tiles_x, rest_ = tile_ / tiles_x;                                \
     lb = rest_ / tiles_y; lm0 = (rest_ % tiles_y) * BM; lt0 = tx_ * BN;                      \
-    wlane = a.w + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + lm0 + wq) * 4;    \
+    wlane = (PREC == 3 ? a.w_split : a.w) + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + lm0 + wq) * 4; \
     xb = a.x + (int64_t)lb * a.x_bstride;                                                    \
     const int len_in_ = a.in_lens ? a.in_lens[lb] : 0x7fffffff;                              \
     int P = tid / XL, col = tid - P * XL;                                                    \
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           }                                                                                  \
           _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) v[s4] = lrelu(v[s4], a.in_slope); \
         }                                                                                    \
-        (XS)[P * XL + col] = v;                                                              \
+        (XS)[P * XL + col] = PREC == 3 ? split_slot(v) : v;                                  \
       }                                                                                      \
       col += NT;                                                                             \
       _Pragma("unroll") for (int w = 0; w < NT / 128; ++w)                                   \
@@ -467,7 +480,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
         const int nsteps = a.K * G;
         const f32x4* wbase = Ws + hl * BM + wm * 32 * WM + l31;       // + step * 2 * BM
         const f32x4* xbase = Xs + hl * XL + wn * 32 * WN + l31;       // + g * 2 * XL + tap * dil
-        if (nact == WM) {
+        // (split-bf16: a wave with one real row tile takes the same loop — its second tile's weights are the
+        // zero rows of the padded slab — because the half-height loop below reads the slots as fp32)
+        if (nact == WM || (PREC == 3 && nact > 0)) {
           f32x4 a0[WM], b0[WN], a1[WM], b1[WN];
 #define MBV_LOAD_AB(ST, AV, BV)                                                   \
           {                                                                        \
@@ -519,8 +534,8 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
             // buy a loop without exec-mask juggling around every MFMA
             static_assert(NWN == 4, "");
             if constexpr (PREC == 3) {
-              // split-bf16: two steps (16 K-values per lane half) per MFMA; no operand double-buffering (the
-              // registers go to the split planes), the other wave of the SIMD covers the LDS latency
+              // split-bf16: two steps (16 K-values per lane half) per MFMA; the slots are already
+              // [hi x 4 | mid x 4] (see split_slot): an operand is two slots' halves, nothing to compute
               if (nj > 0) {
                 for (int st = 0; st < nsteps; st += 2) {
                   f32x4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];
@@ -535,9 +550,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
                   }
                   bf16x8 ah[WM], am[WM], bh[WN], bm[WN];
 #pragma unroll
-                  for (int i = 0; i < WM; ++i) split_bf16(ra0[i], ra1[i], ah[i], am[i]);
+                  for (int i = 0; i < WM; ++i) { ah[i] = plane_of<0>(ra0[i], ra1[i]); am[i] = plane_of<1>(ra0[i], ra1[i]); }
 #pragma unroll
-                  for (int j = 0; j < WN; ++j) split_bf16(rb0[j], rb1[j], bh[j], bm[j]);
+                  for (int j = 0; j < WN; ++j) { bh[j] = plane_of<0>(rb0[j], rb1[j]); bm[j] = plane_of<1>(rb0[j], rb1[j]); }
                   // three rounds over the six accumulators: consecutive MFMAs never share one
 #pragma unroll
                   for (int i = 0; i < WM; ++i)
@@ -868,6 +883,9 @@ static void launch_one(const ConvArgs& a, hipStream_t s) {
         case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE, 3>(a, s); return;
         case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID, 3>(a, s); return;
         case EPI_RESID_ACC: launch_epi<WM, WN, CK, NWN, EPI_RESID_ACC, 3>(a, s); return;
+        case EPI_CONVT:
+          if constexpr (CK == 16) { launch_epi<WM, WN, CK, NWN, EPI_CONVT, 3>(a, s); return; }
+          break;
         default: break;
       }
     }

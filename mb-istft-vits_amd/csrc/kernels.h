@@ -74,6 +74,7 @@ struct ConvArgs {
   int convt_u;             // EPI_CONVT: upsampling stride (4 or 8)
   int splitk;              // 1: split-K allowed for this launch (mbv_set_option "splitk" / MBV_CONV_SPLITK)
   int prec;                // 0: exact fp32 MFMA (default); 3: opt-in split-bf16, three products (mbv_set_option "conv_bf16")
+  const float* w_split;    // prec == 3: the same packed weights as [bf16 hi x 4 | bf16 mid x 4] slots (launch_split_planes)
   // EPI_LN
   const float* ln_gamma;   // [M]
   const float* ln_beta;    // [M]
@@ -138,6 +139,7 @@ void launch_convt(const ConvTArgs& a, hipStream_t s);
 void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, float* x, int* lens32,
                   int* bad, int B, int T, int H, int n_vocab, hipStream_t s);
 // y = LN_c( a (+ r) [relu] ) * gamma + beta  [* mask]
+void launch_split_planes(const float* src, float* dst, size_t n_floats, hipStream_t s);   // fp32 slots -> [hi x 4 | mid x 4] bf16
 void launch_layernorm(const float* a, const float* r, const float* gamma, const float* beta,
                       float* y, int B, int C, int T, int pre_relu, const int* out_lens,
                       hipStream_t s);

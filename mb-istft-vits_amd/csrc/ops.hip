@@ -38,6 +38,34 @@ void launch_embed(const int64_t* ids, const int64_t* lens, const float* emb, flo
 }
 
 // ---------------------------------------------------------------------------
+// Split-bf16 copy of the packed conv weights (opt-in conv_bf16 mode, conv1d.hip): every 16-byte slot of
+// four fp32 K-values becomes [bf16 hi x 4 | bf16 mid x 4], hi = bf16(x), mid = bf16(x - hi) — the layout
+// the conv kernel also gives its input window in that mode, so an MFMA operand is two slots' halves.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* src, float4* dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = src[i];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    bf16x4_t hi, mid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const __bf16 h = (__bf16)x[k];
+      hi[k] = h;
+      mid[k] = (__bf16)(x[k] - (float)h);
+    }
+    struct { bf16x4_t h, m; } o{hi, mid};
+    dst[i] = __builtin_bit_cast(float4, o);
+  }
+}
+void launch_split_planes(const float* src, float* dst, size_t n_floats, hipStream_t s) {
+  const size_t n4 = n_floats / 4;
+  const int grid = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), n4);
+}
+
+// ---------------------------------------------------------------------------
 // Channel LayerNorm (modules.py:29-32), eps 1e-5, two-pass statistics like
 // F.layer_norm.  Fused: residual add (attentions.py:41,45), ReLU in front
 // (models.py:129-130), mask behind (attentions.py:46).
