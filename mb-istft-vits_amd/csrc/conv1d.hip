@@ -526,55 +526,45 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           }
           // (256-thread shapes only: in the 512-thread shape the second loop body costs ~100 registers
           // of live ranges and the kernel spills)
-          if constexpr (NWN == 2) {
+          // split-bf16: two steps (16 K-values per lane half) per MFMA; the slots are already
+          // [hi x 4 | mid x 4] (see split_slot): an operand is two slots' halves, nothing to compute.
+          // No column test in either shape: columns past the sequence end are staged as zeros.
+#define MBV_BF16_LOOP()                                                                                   \
+          for (int st = 0; st < nsteps; st += 2) {                                                         \
+            f32x4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];                                                      \
+            MBV_LOAD_AB(st, ra0, rb0);                                                                     \
+            if (st + 1 < nsteps) {                                                                         \
+              MBV_LOAD_AB(st + 1, ra1, rb1);                                                               \
+            } else {                                   /* odd step count: the second half of the K-values is absent */ \
+              _Pragma("unroll") for (int i = 0; i < WM; ++i) ra1[i] = f32x4{0.f, 0.f, 0.f, 0.f};           \
+              _Pragma("unroll") for (int j = 0; j < WN; ++j) rb1[j] = f32x4{0.f, 0.f, 0.f, 0.f};           \
+            }                                                                                              \
+            bf16x8 ah[WM], am[WM], bh[WN], bm[WN];                                                         \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i) { ah[i] = plane_of<0>(ra0[i], ra1[i]); am[i] = plane_of<1>(ra0[i], ra1[i]); } \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j) { bh[j] = plane_of<0>(rb0[j], rb1[j]); bm[j] = plane_of<1>(rb0[j], rb1[j]); } \
+            /* three rounds over the accumulators: consecutive MFMAs never share one */                   \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                 \
+              _Pragma("unroll") for (int j = 0; j < WN; ++j)                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);     \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                 \
+              _Pragma("unroll") for (int j = 0; j < WN; ++j)                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);     \
+            _Pragma("unroll") for (int i = 0; i < WM; ++i)                                                 \
+              _Pragma("unroll") for (int j = 0; j < WN; ++j)                                               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
+          }
+          if constexpr (PREC == 3) {
+            if (nj > 0) { MBV_BF16_LOOP() }
+          } else if constexpr (NWN == 2) {
             if (nj == WN) MBV_STEP_LOOP(true) else MBV_STEP_LOOP(false)
           } else {
             // 512-thread shape: no column test at all — columns past the end of the sequence are
             // staged as zeros and never stored, so the few MFMAs they cost on the last tile of a row
             // buy a loop without exec-mask juggling around every MFMA
             static_assert(NWN == 4, "");
-            if constexpr (PREC == 3) {
-              // split-bf16: two steps (16 K-values per lane half) per MFMA; the slots are already
-              // [hi x 4 | mid x 4] (see split_slot): an operand is two slots' halves, nothing to compute
-              if (nj > 0) {
-                for (int st = 0; st < nsteps; st += 2) {
-                  f32x4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];
-                  MBV_LOAD_AB(st, ra0, rb0);
-                  if (st + 1 < nsteps) {
-                    MBV_LOAD_AB(st + 1, ra1, rb1);
-                  } else {                                   // odd step count: the second half of the K-values is absent
-#pragma unroll
-                    for (int i = 0; i < WM; ++i) ra1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < WN; ++j) rb1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                  }
-                  bf16x8 ah[WM], am[WM], bh[WN], bm[WN];
-#pragma unroll
-                  for (int i = 0; i < WM; ++i) { ah[i] = plane_of<0>(ra0[i], ra1[i]); am[i] = plane_of<1>(ra0[i], ra1[i]); }
-#pragma unroll
-                  for (int j = 0; j < WN; ++j) { bh[j] = plane_of<0>(rb0[j], rb1[j]); bm[j] = plane_of<1>(rb0[j], rb1[j]); }
-                  // three rounds over the six accumulators: consecutive MFMAs never share one
-#pragma unroll
-                  for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                  for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                  for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-              }
-            } else {
-              if (nj > 0) MBV_STEP_LOOP(true)
-            }
+            if (nj > 0) MBV_STEP_LOOP(true)
           }
+#undef MBV_BF16_LOOP
 #undef MBV_STEP_LOOP
 #undef MBV_LOAD_AB
 #undef MBV_MMA
@@ -875,9 +865,9 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
 // SGPRs spilled to VGPR lanes) and a k=3 conv spent a quarter of its time walking that code.
 template <int WM, int WN, int CK, int NWN>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
-  // opt-in split-bf16 (ConvArgs::prec): built for the 128 x 384 shape and the epilogues of the decoder's
-  // ResBlock convs, where the time is; everything else stays exact fp32
-  if constexpr (NWN == 4 && WM == 2 && WN == 3 && CK <= 16) {
+  // opt-in split-bf16 (ConvArgs::prec): built for the 128-row shapes, k > 1, and the epilogues of the
+  // decoder's convs, where the time is; everything else stays exact fp32
+  if constexpr (WM == 2 && CK <= 16) {
     if (a.prec == 3) {
       switch (a.epi) {
         case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE, 3>(a, s); return;

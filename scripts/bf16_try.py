@@ -5,7 +5,7 @@ import numpy as np, torch
 from gpu_util import make_net
 from mb_istft_vits_amd import synth
 def rms(a): return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-for cfg_name, B in (("ljs_mb_istft_vits", 64), ("ljs_ms_istft_vits", 64), ("uudb_ms_istft_vits_ms", 32)):
+for cfg_name, B in (("ljs_mb_istft_vits", 64), ("ljs_mb_istft_vits", 16), ("ljs_mb_istft_vits", 4), ("uudb_ms_istft_vits_ms", 32), ("ljs_istft_vits", 32)):
     net, sd = make_net(cfg_name)
     x, xl, sid = synth.synthetic_batch(net.cfg, B, 200, seed=0)
     xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()

@@ -54,17 +54,18 @@ def test_conv1d_mfma(net, B, Cin, Cout, T, K, dil, slope):
     assert err <= 2e-5 * rms(ref.numpy()) + 1e-7, err
 
 
-@pytest.mark.parametrize("Cin,Cout,T,K,dil", [(128, 128, 3072, 7, 3), (128, 128, 3100, 11, 5), (256, 256, 1536, 3, 1),
-                                             (128, 128, 3072, 3, 5), (128, 72, 3001, 7, 1)])
-def test_conv1d_split_bf16_mode(Cin, Cout, T, K, dil):
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil", [(64, 128, 128, 3072, 7, 3), (64, 128, 128, 3100, 11, 5), (64, 256, 256, 1536, 3, 1),
+                                               (64, 128, 128, 3072, 3, 5), (64, 128, 72, 3001, 7, 1),
+                                               (3, 128, 128, 1001, 7, 5), (2, 256, 256, 517, 11, 1), (5, 192, 512, 300, 7, 1),
+                                               (2, 128, 96, 333, 3, 3)])
+def test_conv1d_split_bf16_mode(B, Cin, Cout, T, K, dil):
     """Opt-in `conv_bf16 = 3` (hi/mid bf16 planes, three products, fp32 accumulation on the bf16 MFMA) in the
-    128 x 384 conv kernel: launches large enough to take that shape (>= 512 tiles), against torch's fp32
-    conv on the GPU.  Bar for this mode: 3e-5 of the output RMS per conv (measured ~5e-6; the exact path's
+    128-row conv kernels — launches large enough for the 128 x 384 shape (>= 512 tiles) and small ones on the
+    128 x 128 shape (incl. a half-height last row tile) — against torch's fp32 conv on the GPU.  Bar for this mode: 3e-5 of the output RMS per conv (measured ~5e-6; the exact path's
     bar is 2e-5 with ~3e-7 measured) — and the mode must actually be taken (the result differs from the
     exact path's) and must leave the default untouched."""
     from gpu_util import make_net, op_conv1d
     net = make_net("ljs_mini_mb_istft_vits")[0]
-    B = 64
     g = torch.Generator(device="cuda").manual_seed(Cin + T + K)
     x = torch.randn(B, Cin, T, device="cuda", generator=g)
     rs = np.random.RandomState(K * 100 + dil)
