@@ -391,6 +391,33 @@ def test_split_bf16_mode_meets_the_waveform_bar():
     assert rms(o[pick].cpu().numpy() - ref["o"].numpy()) < 1e-4
 
 
+def test_split_bf16_mode_follows_weight_refreshes():
+    """The mode reads a second, split copy of the packed weights; reloading weights into the same handle must
+    rebuild it: after an in-place change of a decoder weight the split-mode result equals that of a fresh
+    model built with the changed weights (and differs from the result before the change)."""
+    from gpu_util import make_net
+    net, sd = make_net("ljs_mini_mb_istft_vits")
+    rs = np.random.RandomState(7)
+    z = torch.from_numpy(rs.standard_normal((3, 192, 50)).astype(np.float32)).cuda()
+    net.set_option("conv_bf16", 3)
+    before = net.dec(z)[0].clone()
+    key = next(k for k in sd if k.startswith("dec.resblocks.0.convs1.0") and k.endswith("weight_g"))
+    sd2 = {k: v.copy() for k, v in sd.items()}
+    sd2[key] = (sd2[key] * 1.5).astype(np.float32)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    after = net.dec(z)[0].clone()
+    fresh, _ = make_net("ljs_mini_mb_istft_vits")
+    fresh.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    fresh = fresh.cuda()
+    fresh.set_option("conv_bf16", 3)
+    want = fresh.dec(z)[0]
+    assert not torch.equal(before, after)
+    assert torch.equal(after, want)
+    net.set_option("conv_bf16", 0)
+    exact = net.dec(z)[0]
+    assert not torch.equal(exact, after) and rms((exact - after).cpu().numpy()) < 2e-5
+
+
 def test_resblock_streams_are_bitwise_the_one_stream_schedule():
     """Small launches run the three ResBlocks of a decoder stage on three streams (capi.hip run_decoder):
     same kernels, the running-sum updates chained in the one-stream order, so every output must be
