@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Exact fp32 vs the opt-in split-bf16 conv mode (`conv_bf16 = 3`) on a few configurations: ms per infer (sum of the
+stage timers), decoder stage, and the distance between the two waveforms.  usage: python scripts/conv_bf16_ab.py"""
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from gpu_util import make_net
