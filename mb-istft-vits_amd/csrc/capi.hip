@@ -1043,7 +1043,12 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
   // two-launch path is only taken when MBV_WN_SMALL asks for it: launches below that many 32-frame tiles)
   static const int small_units = [] { const char* e = getenv("MBV_WN_SMALL"); return e ? atoi(e) : 0; }();
   const bool small = (long)B * ((T + 31) / 32) < small_units;
-  if (m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small)) {
+  // (split-bf16 mode: the two-launch layer on the conv kernel, which has the mode — from ~12 k frames up the
+  // gate conv + res/skip conv in split-bf16 beat the fused exact layer: ljs_mb B=64 23.6 -> 22.3 ms per infer,
+  // uudb B=32 15.7 -> 14.9; B=16: 8.9 -> 9.0, so smaller launches keep the fused layer.  MBV_WN_BF16=0: never)
+  static const int wn_bf16 = [] { const char* e = getenv("MBV_WN_BF16"); return e ? atoi(e) : 1; }();
+  const bool two_launch_bf16 = wn_bf16 && m->Wsplit(0) != nullptr && (long)B * T >= 12288;
+  if (!two_launch_bf16 && m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small)) {
     int* hmap = ustart + B + 1;
     launch_wn_units(lens, B, T, ustart, hmap, s);
     float* hin = hbuf;

@@ -867,16 +867,23 @@ template <int WM, int WN, int CK, int NWN>
 static void launch_one(const ConvArgs& a, hipStream_t s) {
   // opt-in split-bf16 (ConvArgs::prec): built for the 128-row shapes, k > 1, and the epilogues of the
   // decoder's convs, where the time is; everything else stays exact fp32
-  if constexpr (WM == 2 && CK <= 16) {
+  if constexpr (WM == 2) {
     if (a.prec == 3) {
-      switch (a.epi) {
-        case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE, 3>(a, s); return;
-        case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID, 3>(a, s); return;
-        case EPI_RESID_ACC: launch_epi<WM, WN, CK, NWN, EPI_RESID_ACC, 3>(a, s); return;
-        case EPI_CONVT:
-          if constexpr (CK == 16) { launch_epi<WM, WN, CK, NWN, EPI_CONVT, 3>(a, s); return; }
-          break;
-        default: break;
+      if constexpr (CK <= 16) {
+        switch (a.epi) {
+          case EPI_STORE: launch_epi<WM, WN, CK, NWN, EPI_STORE, 3>(a, s); return;
+          case EPI_RESID: launch_epi<WM, WN, CK, NWN, EPI_RESID, 3>(a, s); return;
+          case EPI_RESID_ACC: launch_epi<WM, WN, CK, NWN, EPI_RESID_ACC, 3>(a, s); return;
+          case EPI_CONVT:
+            if constexpr (CK == 16) { launch_epi<WM, WN, CK, NWN, EPI_CONVT, 3>(a, s); return; }
+            break;
+          case EPI_GATE:                             // the two-launch WN layer of the flows in this mode (capi.hip run_wn)
+            if constexpr (CK == 16) { launch_epi<WM, WN, CK, NWN, EPI_GATE, 3>(a, s); return; }
+            break;
+          default: break;
+        }
+      } else {
+        if (a.epi == EPI_RES_SKIP) { launch_epi<WM, WN, CK, NWN, EPI_RES_SKIP, 3>(a, s); return; }
       }
     }
   }
