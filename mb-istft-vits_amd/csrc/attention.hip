@@ -21,11 +21,17 @@
 // every score tile twice).  The relative-key logits are one extra MFMA tile
 // (rows = the 9 embeddings), the relative-value term is accumulated as 9 band
 // weights per query and applied to O^T at the end.
+// r02h: Q lives in LDS as a k-interleaved image (one 16-byte read = four k-steps; it used to take 48 of the
+// 254 registers), the score tile and the relative-key logits accumulate in 2 / 4 interleaved MFMA chains
+// (a dependent fp32 32x32x2 MFMA issues ~250 cycles after its predecessor), k-steps past the head dimension
+// multiply zeros instead of being tested for, and V never touches LDS: the four k-steps 4q .. 4q + 3 of the
+// P.V product are four consecutive keys of a lane's V row, i.e. one 16-byte load straight into the operand.
 #include "kernels.h"
 
 namespace mbv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int acc_row(int reg, int hl) { return (reg & 3) + 8 * (reg >> 2) + 4 * hl; }
 
@@ -39,15 +45,13 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
                                                            float* __restrict__ o, int H, int n_heads,
                                                            int T) {
   constexpr int DMAX = DT * 32;
-  constexpr int VS = 33;                              // padded LDS row: conflict-free column reads
   constexpr int NW = ATT_NW;
   constexpr int PER = DT * 16 + 9;                     // floats per lane in the final reduction
-  constexpr int VALL = NW * DMAX * VS > (NW - 1) * PER * 64 ? NW * DMAX * VS : (NW - 1) * PER * 64;
-  __shared__ float Vall[VALL];                         // per-wave V tile; reused for the final reduction
+  constexpr int VALL = (NW - 1) * PER * 64;
+  __shared__ float Vall[VALL];                         // the final reduction's hand-over
   __shared__ float stat[NW][2][64];                    // per-wave (max, sum) of pass 1
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, l31 = lane & 31;
-  float* const Vs = Vall + wave * DMAX * VS;
   const int b = blockIdx.z, head = blockIdx.y;
   const int d = H / n_heads;
   const int tq0 = blockIdx.x * 32;
@@ -72,25 +76,46 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, d * T * 4, kRsrcFlags);
   const int row2 = 2 * T * 4;                         // bytes between k-steps (two rows)
 
-  // Q fragments (B operand): B[k = 2s+hl][j = l31] = q[2s+hl][tq] / sqrt(d)
-  float qf[DMAX / 2];
+  // Q fragments (B operand): B[k = 2s+hl][j = l31] = q[2s+hl][tq] / sqrt(d), in LDS, k-interleaved like the
+  // conv kernels' images: one 16-byte read = the four k-steps 4g .. 4g + 3 of a lane.  (In registers they
+  // were 48 of the kernel's 254; that room now holds a second score accumulator and V.)
+  constexpr int QG = DMAX / 8;
+  __shared__ f32x4 Qs[QG * 2 * 32];
+  for (int e = threadIdx.x; e < QG * 2 * 32; e += 64 * NW) {
+    const int g = e >> 6, h = (e >> 5) & 1, t = tq0 + (e & 31);
+    f32x4 v;
 #pragma unroll
-  for (int s = 0; s < DMAX / 2; ++s)
-    qf[s] = (s < nsteps && tq < T) ? qb[(int64_t)(2 * s + hl) * T + tq] / inv : 0.f;
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int k = 4 * g + s4;
+      v[s4] = (k < nsteps && t < T) ? qb[(int64_t)(2 * k + h) * T + t] / inv : 0.f;
+    }
+    Qs[e] = v;
+  }
+  __syncthreads();
+  const f32x4* const ql = Qs + hl * 32 + l31;          // + 64 g
 
   // ---- relative-key logits: R^T[r][tq] = sum_d Ek[r][d] q[d][tq] ------------
+  // (four interleaved MFMA chains: an fp32 32x32x2 MFMA feeds the next one on the same accumulator only
+  // ~250 cycles later, see conv1d_narrow.hip, and nothing else runs in this prologue)
   float rel[9];
   {
-    f32x16 acc;
+    f32x16 acc, accb[3];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[0][r] = 0.f; accb[1][r] = 0.f; accb[2][r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < DMAX / 2; ++s) {
-      if (s < nsteps) {
-        const float av = l31 < 9 ? emb_k[l31 * d + 2 * s + hl] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qf[s], acc, 0, 0, 0);
+    for (int g = 0; g < QG; ++g) {
+      const f32x4 qv = ql[64 * g];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        // (k-steps past the head dimension multiply the zeros of the Q image: no test between the MFMAs)
+        const int kk = min(2 * (4 * g + s4) + hl, d - 1);
+        const float av = l31 < 9 ? emb_k[l31 * d + kk] : 0.f;
+        if (s4 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qv[s4], acc, 0, 0, 0);
+        else accb[s4 - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qv[s4], accb[s4 - 1], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) acc[r] = (acc[r] + accb[0][r]) + (accb[1][r] + accb[2][r]);   // (only rows 0-8 are read)
     // rows 0-3 / 8 live in half 0 (regs 0-3 / 4), rows 4-7 in half 1 (regs 0-3)
     float mine[5], other[5];
 #pragma unroll
@@ -113,17 +138,26 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
     const int koff = (kt < ntiles && tkl < T) ? (hl * T + tkl) * 4 : kOob;
 #pragma unroll
     for (int s = 0; s < DMAX / 2; ++s)
-      kf[s] = s < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krsrc, koff, s * row2, 0))
-                         : 0.f;
+      kf[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krsrc, koff, s * row2, 0));   // rows past d: past the slice, read 0
   };
   // score tile for key tile kt from kf, masked; rows beyond T get -inf (absent keys)
   auto score_tile = [&](int kt, f32x16& S) {
     const int tk0 = kt * 32;
+    // two interleaved chains (with the wave sharing the SIMD: four)
+    f32x16 S2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { S[r] = 0.f; S2[r] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < DMAX / 2; ++s)
-      if (s < nsteps) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], S, 0, 0, 0);
+    for (int g = 0; g < QG; ++g) {
+      const f32x4 qv = ql[64 * g];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 & 1) S2 = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[4 * g + s4], qv[s4], S2, 0, 0, 0);
+        else S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[4 * g + s4], qv[s4], S, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] += S2[r];
     const bool near = (tk0 - tq0) <= 35 && (tq0 - tk0) <= 35;   // wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -160,24 +194,23 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
   load_k(wave);
   for (int kt = wave; kt < ntiles; kt += NW) {
     const int tk0 = kt * 32;
-    // V[dd][tk0 + l31] of this tile -> registers (consumed after the softmax arithmetic)
-    float vf[DMAX / 2];
+    // V of this tile straight into the A operands of O^T = V P^T: k-step s of that product is key
+    // (s & 3) + 8 (s >> 2) + 4 hl of the tile (the accumulator row of probability register s), so the four
+    // k-steps 4 q .. 4 q + 3 of a lane are FOUR CONSECUTIVE keys of its V row — one 16-byte load, no LDS.
+    // (Keys past T read the next row's first values or, past the slice, zeros: finite, and their
+    // probabilities are exactly 0.)  Requested before the score MFMAs, consumed after the softmax.
+    f32x4 vf[DT][4];
     {
-      const int voff = tk0 + l31 < T ? (hl * T + tk0 + l31) * 4 : kOob;
 #pragma unroll
-      for (int it = 0; it < DMAX / 2; ++it)
-        vf[it] = it < nsteps ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, voff, it * row2, 0)) : 0.f;
+      for (int t = 0; t < DT; ++t) {
+        const int voff = ((t * 32 + l31) * T + tk0 + 4 * hl) * 4;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          vf[t][q4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, voff, q4 * 32, 0));
+      }
     }
     f32x16 S;
     score_tile(kt, S);
-    load_k(kt + NW);                       // (past the last tile: nothing is read)
-    // V -> this wave's Vs[dd][.] as soon as the score chain is issued (it had ~3 k cycles to arrive;
-    // parking it in registers through the softmax arithmetic as well costs a second wave per SIMD).
-    // Wave-private: the LDS accesses of one wave are ordered, no workgroup barrier — the waves run
-    // different trip counts.
-#pragma unroll
-    for (int it = 0; it < DMAX / 2; ++it) Vs[(it * 2 + hl) * VS + l31] = vf[it];
-
     float tmax = S[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
@@ -204,18 +237,13 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
         for (int q = 0; q < 9; ++q) wb[q] += (rr == q) ? S[r] : 0.f;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    load_k(kt + NW);                       // next tile's K under the P.V MFMAs (past the last tile: nothing is read)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int tkl = acc_row(s, hl);             // key (within tile) this half supplies at k-step s
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const float av = Vs[(t * 32 + l31) * VS + tkl];
-        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, S[s], O[t], 0, 0, 0);
-      }
+      for (int t = 0; t < DT; ++t)
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][s >> 2][s & 3], S[s], O[t], 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();              // the PV reads are done before the next tile's V lands
   }
   sum += __shfl_xor(sum, 32);
 #pragma unroll
