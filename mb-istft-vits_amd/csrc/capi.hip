@@ -1324,6 +1324,14 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   if (c.n_speakers > 0 && !sid) return m->fail("sid is required when n_speakers > 0 (models.py:704-705)");
   if (c.n_speakers > 0 && !m->emb_g.present) return m->fail("n_speakers == 1: the reference has no emb_g either");
   DEVICE_GUARD(m);
+  // The text encoder and the duration predictor ALWAYS run exact: the durations (ceil of an exponential) must
+  // not depend on the opt-in split-bf16 mode, which is for the waveform path only.  (Long texts, T > 256,
+  // use the conv kernels that have the mode; short ones the narrow kernel, which does not.)
+  struct ExactScope {
+    mbv_model* m; int saved;
+    explicit ExactScope(mbv_model* mm) : m(mm), saved(mm->conv_bf16) { m->conv_bf16 = 0; }
+    ~ExactScope() { m->conv_bf16 = saved; }
+  } exact_scope(m);
   hipStream_t s = (hipStream_t)stream;
   const int H = c.hidden_channels, I = c.inter_channels, Fc = c.filter_channels, gin = c.gin_channels;
   const size_t BT = (size_t)B * T;

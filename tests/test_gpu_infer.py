@@ -391,6 +391,26 @@ def test_split_bf16_mode_meets_the_waveform_bar():
     assert rms(o[pick].cpu().numpy() - ref["o"].numpy()) < 1e-4
 
 
+def test_split_bf16_mode_leaves_long_text_durations_exact():
+    """Texts longer than 256 tokens run the text encoder on the conv kernels that have the split-bf16 mode;
+    `mbv_encode` must keep them exact all the same: durations and the encoder outputs are bitwise those of
+    the exact mode, only the waveform path differs."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, sd = make_net("ljs_mb_istft_vits")
+    x, xl, _ = synth.synthetic_batch(net.cfg, 8, 300, seed=3)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    a, ya = net.infer_with_lengths(xg, xlg, None, noise_scale=0, length_scale=1)
+    net.set_option("conv_bf16", 3)
+    try:
+        b, yb = net.infer_with_lengths(xg, xlg, None, noise_scale=0, length_scale=1)
+    finally:
+        net.set_option("conv_bf16", 0)
+    assert torch.equal(ya, yb) and torch.equal(a[4], b[4])                # durations, attention path
+    assert torch.equal(a[6][2], b[6][2]) and torch.equal(a[6][3], b[6][3])  # m_p, logs_p
+    assert not torch.equal(a[0], b[0]) and rms((a[0] - b[0]).cpu().numpy()) < 2e-5
+
+
 def test_split_bf16_mode_follows_weight_refreshes():
     """The mode reads a second, split copy of the packed weights; reloading weights into the same handle must
     rebuild it: after an in-place change of a decoder weight the split-mode result equals that of a fresh
