@@ -66,12 +66,19 @@ def test_two_rank_hip_sharded_infer_equals_full_batch(tmp_path):
         (o, *_), ylen = net.infer_with_lengths(xg, xlg, sidg, noise_scale=0, length_scale=1)
         assert torch.equal(res[0][name]["ylen"], ylen.cpu()), name
         assert res[0][name]["o"].shape == o.shape, name
-        assert torch.equal(res[0][name]["o"], o.cpu()), name          # bitwise: global T' pad, same kernels
+        if os.environ.get("MBV_CONV_SPLITK", "0") not in ("", "0"):
+            # the opt-in low-latency mode picks kernels by launch size: a shard equals the full batch within rounding
+            assert float((res[0][name]["o"] - o.cpu()).abs().max()) < 2e-5, name
+        else:
+            assert torch.equal(res[0][name]["o"], o.cpu()), name      # bitwise: global T' pad, same kernels
         if name == "mini_b5":
             torch.manual_seed(77)
             torch.cuda.manual_seed(77)
             o_n = net.infer(xg, xlg, sidg, noise_scale=0.6, length_scale=1)[0]
-            assert torch.equal(res[0]["mini_b5_noise"]["o"], o_n.cpu())
+            if os.environ.get("MBV_CONV_SPLITK", "0") not in ("", "0"):
+                assert float((res[0]["mini_b5_noise"]["o"] - o_n.cpu()).abs().max()) < 2e-5
+            else:
+                assert torch.equal(res[0]["mini_b5_noise"]["o"], o_n.cpu())
             assert not torch.equal(o_n, o)
 
 
