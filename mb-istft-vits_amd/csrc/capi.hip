@@ -113,6 +113,7 @@ struct mbv_model {
   int dec_streams = 1;          // option "dec_streams" / MBV_DEC_STREAMS: 0 = always one stream
   int conv_bf16 = 0;            // option "conv_bf16" / MBV_CONV_BF16: 3 = opt-in split-bf16 arithmetic in the large conv launches
   bool ev_ok = false, ev_a = false, ev_b = false, evk_set = false;
+  bool evk_split = false;          // the last decoder run split its batch: evk[1] does not separate conv stack and iSTFT
 
   int fail(const char* fmt, ...) {
     char buf[1024];
@@ -891,6 +892,10 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       HIPCHK(m, hipEventRecord(m->ev_fork, s_main));
       for (auto& st : m->aux) HIPCHK(m, hipStreamWaitEvent(st, m->ev_fork, 0));
     }
+    // (an early return between the fork and the join below would leave work queued on the aux streams that
+    // the caller's stream never waits for, while the next call reuses this scratch: the loop runs in a lambda
+    // and a failure drains the aux streams first)
+    auto resblocks = [&]() -> int {
     for (int j = 0; j < 3; ++j) {
       const auto& R = m->rb[i * 3 + j];
       hipStream_t s = (conc && j > 0) ? m->aux[j - 1] : s_main;   // this ResBlock's stream
@@ -962,6 +967,12 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
         state = r;
       }
     }
+    return 0;
+    };
+    if (resblocks()) {
+      if (conc) for (auto& st : m->aux) (void)hipStreamSynchronize(st);
+      return 1;
+    }
     if (conc) HIPCHK(m, hipStreamWaitEvent(s_main, m->ev_rb[2], 0));
     m->stages[i == 0 ? "dec_res_0" : "dec_res_1"] = {xs, (int64_t)n};
     cur = xs;
@@ -995,7 +1006,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
       launch_conv1d(a, s);
     }
-    if (b0 == 0) HIPCHK(m, hipEventRecord(m->evk[1], s));
+    if (b0 == 0) HIPCHK(m, hipEventRecord(m->evk[1], s));   // (a split run interleaves conv_post and iSTFT launches: evk_split below)
     if (sb) {
       IstftSbArgs ia{};
       ia.x_post = xpost; ia.o = o + (size_t)b0 * M4;
@@ -1020,6 +1031,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   m->xpost_rows = prow;
   HIPCHK(m, hipEventRecord(m->evk[2], s));
   m->evk_set = true;
+  m->evk_split = Bc < B;
   return 0;
 }
 
@@ -1123,7 +1135,12 @@ size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td) {
     const long conv_tiles = (long)B * (long)((Lo + 383) / 384) * (long)((ch + 127) / 128);
     n += (conv_tiles <= 192 ? 8 : 4) * (size_t)B * ch * Lo;
   }
-  n += (size_t)B * 72 * (us * us * Td + 1) + (size_t)B * 256 * Td;
+  {   // x_post: run_decoder takes at most the sub-batch that stays below 2 GiB (its Bc; the option can only lower it)
+    const size_t utt = 72 * (us * us * Td + 1);
+    size_t bc = utt ? ((size_t)(1ULL << 31) - 1) / (utt * sizeof(float)) : (size_t)B;
+    if (bc < 1) bc = 1;
+    n += (bc < (size_t)B ? bc : (size_t)B) * utt + (size_t)B * 256 * Td;
+  }
   n += 6 * (size_t)B * C0;                                     // cond vectors
   return n * sizeof(float) + 64 * 256 + 32 * 256;              // + the 256-byte alignment of every take
 }
@@ -1214,6 +1231,7 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
 int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!m) return 1;
   if (!name) return m->fail("mbv_set_option: name is NULL");
+  DEVICE_GUARD(m);                 // conv_bf16 allocates and launches on the model's device, whatever the caller's current one
   if (!strcmp(name, "splitk")) { m->splitk = value != 0; return 0; }
   if (!strcmp(name, "istft_exact")) { m->exact_math = value != 0; return 0; }
   if (!strcmp(name, "wn_fused")) { m->wn_fused = value != 0; return 0; }
@@ -1578,6 +1596,9 @@ int mbv_kernel_times_ms(mbv_model* m, float out[2]) {
   if (!m || !out) return 1;
   DEVICE_GUARD(m);
   if (!m->evk_set) return m->fail("no decoder run to time");
+  if (m->evk_split)
+    return m->fail("kernel times unavailable: the last decoder run split its batch into sub-batches (x_post >= 2 GiB or "
+                   "xpost_chunk_bytes), so conv_post and iSTFT launches interleave");
   HIPCHK(m, hipEventSynchronize(m->evk[2]));
   HIPCHK(m, hipEventElapsedTime(&out[0], m->evk[0], m->evk[1]));
   HIPCHK(m, hipEventElapsedTime(&out[1], m->evk[1], m->evk[2]));

@@ -52,6 +52,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// In-kernel timeline (scripts/conv_stamps.hip builds this file with -DMBV_CONV_STAMPS): threads 0 and 256 of
+// every workgroup (wave 0 and its SIMD partner wave 4 in the 512-thread shape) append the 100 MHz wall clock at
+// the phase boundaries named at the call sites; 512 slots per sampled thread, slot 0 = count.  Kept in LDS until
+// the workgroup ends: a global store per stamp would sit in front of the kernel's own s_waitcnt vmcnt(0)s and
+// stretch exactly the phases being measured.  Without the macro nothing of this exists in the kernels.
+#ifdef MBV_CONV_STAMPS
+#define MBV_CSTAMP(ID)                                                                        \
+  if ((tid & 255) == 0 && stamp_n < 511) stamp_lds[tid >> 8][++stamp_n] = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned)(ID);
+#define MBV_CSTAMP_FLUSH()                                                                    \
+  {                                                                                           \
+    if ((tid & 255) == 0) stamp_lds[tid >> 8][0] = stamp_n;                                   \
+    __syncthreads();                                                                          \
+    unsigned long long* sb_ = reinterpret_cast<unsigned long long*>(a.ws) + (size_t)blockIdx.x * 1024; \
+    for (int e = tid; e < 1024; e += NT) sb_[e] = stamp_lds[e >> 9][e & 511];                 \
+  }
+#else
+#define MBV_CSTAMP(ID)
+#define MBV_CSTAMP_FLUSH()
+#endif
+
 // Opt-in split-bf16 arithmetic (ConvArgs::prec == 3, mbv_set_option "conv_bf16"): x = hi + mid + O(2^-17 x)
 // with hi = bf16(x), mid = bf16(x - hi); a product keeps hi*hi + hi*mid + mid*hi (relative error ~2^-16),
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16 — 3 MFMAs of 32 cycles per 16 K-values instead of 8 of
@@ -208,6 +228,10 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+#ifdef MBV_CONV_STAMPS
+  int stamp_n = 0;
+  __shared__ unsigned long long stamp_lds[2][512];
+#endif
   // 256-thread shapes: wave index made provably uniform, so the nact / nj tests become scalar
   // branches (in the 512-thread shape the extra SGPR pressure makes the kernel spill instead)
   const int wave = NWN == 2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
@@ -431,6 +455,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
     // to reach L2: an epilogue that interleaves the two is a chain of round trips (measured: a
     // quarter of a k=3 conv).  With the reads up here the epilogue is stores only.
     f32x16 acc[WM][WN];
+    MBV_CSTAMP(1)                        // tile start
     // bias (+ per-utterance row terms) of row wrow0 + lane, handed out by cross-lane reads below
     float rowc = 0.f;
     {
@@ -464,6 +489,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
     if constexpr (DB) { MBV_ISSUE_NEXT(); }   // second chunk of this tile (its first is in LDS)
+    MBV_CSTAMP(2)                        // start values requested, second chunk requested
 
     for (int c = c_lo; c < c_hi; ++c, ++q) {
       f32x4* const Xs = lds4 + (DB ? ((q & 1) ? buf_f4 : 0) : 0);           // buffer holding this chunk
@@ -475,6 +501,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
         if (pend_cn >= 0) { MBV_GLDS_W(pend_cn, Wn); }   // its input window is already in flight (xreg)
       }
 
+      MBV_CSTAMP(3)                      // chunk: MFMA loop starts
       if (a.debug != 3) {
         // ---- MFMA over (tap, group) steps; each step = 4 K-steps from one b128 per operand tile
         const int nsteps = a.K * G;
@@ -586,12 +613,17 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
       }
 
       // pend_cn and the cursor depend on blockIdx only: the barriers below are workgroup-uniform
+      MBV_CSTAMP(4)                      // chunk: MFMA loop done
       if constexpr (DB) {
         if (pend_cn >= 0) { MBV_COMMIT(pend_cn, Xn, Wn); }   // other buffer: last read one barrier ago
         pend_cn = -1;
+        MBV_CSTAMP(9)                    // chunk: input window committed
         if constexpr (GLDS) { MBV_GLDS_DRAIN(); }            // this wave's share of the next weight slab has landed
+        MBV_CSTAMP(10)                   // chunk: weight DMA drained
         if (c + 1 < c_hi) { MBV_ISSUE_NEXT(); }              // the last chunk issues AFTER the epilogue
+        MBV_CSTAMP(5)                    // chunk: next chunk committed, the one after requested
         __syncthreads();
+        MBV_CSTAMP(6)                    // chunk: barrier passed
       } else {
         if (pend_cn >= 0) {
           __syncthreads();                          // every wave is done reading the buffer
@@ -605,6 +637,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
     // ---- epilogue ----------------------------------------------------------
     // accumulator layout (32x32 tile): column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // stores only (see the accumulator initialisation above)
+    MBV_CSTAMP(7)                        // epilogue starts
     bool skip_epi = a.debug == 4 && acc[0][0][0] != 12345.678f;         // timing experiment: no epilogue traffic
     if (S > 1) {
       const size_t tile_floats = (size_t)BM * BN;                      // == 16 WM WN NT
@@ -800,7 +833,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
         }
       }
     }
+    MBV_CSTAMP(8)                        // epilogue issued (stores in flight)
   }
+  MBV_CSTAMP_FLUSH()
 #undef MBV_ISSUE_NEXT
 #undef MBV_SETUP_TILE
 #undef MBV_ISSUE
@@ -853,7 +888,12 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // static LDS: the split-K ticket
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+#ifdef MBV_CONV_STAMPS
+                              150 * 1024);                        // static LDS: the ticket + 8 KB of stamps
+#else
+                              160 * 1024 - 256);                  // static LDS: the split-K ticket
+#endif
     attr = true;
   }
   hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,

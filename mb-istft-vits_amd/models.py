@@ -503,7 +503,8 @@ class SynthesizerTrn(nn.Module):
         arithmetic in the large conv launches, see include/mbistft_vits.h).  Kept across weight refreshes; a
         handle re-created on another device starts from the defaults again."""
         h = self._ensure_handle()
-        _capi.check(h, _capi.lib().mbv_set_option(h, name.encode(), int(value)), "mbv_set_option")
+        with torch.cuda.device(self._device()):
+            _capi.check(h, _capi.lib().mbv_set_option(h, name.encode(), int(value)), "mbv_set_option")
 
     def read_stage(self, name):
         """Internal stage tensor of the last call as a flat fp32 tensor (tests/debugging)."""

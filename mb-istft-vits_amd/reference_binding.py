@@ -5,7 +5,7 @@ parameters, its `state_dict`) and only moves the inference computation to the MI
 
     from models import SynthesizerTrn as RefSynth          # the reference's class, unchanged
     from mb_istft_vits_amd.reference_binding import bind
-    SynthesizerTrn = bind(RefSynth)                         # same ctor; infer / infer_z_only / dec on the GPU
+    SynthesizerTrn = bind(RefSynth)                         # same ctor; infer / infer_z_only / voice_conversion / dec(z, g) on the GPU
     net = SynthesizerTrn(len(symbols), ..., **hps.model).cuda().eval()
     utils.load_checkpoint(path, net, None)                  # the reference's loader, unchanged
     audio = net.infer(x, x_lengths, noise_scale=.667, length_scale=1)[0][0, 0]
@@ -17,6 +17,7 @@ runs this file against a golden vector of the reference.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -52,6 +53,7 @@ def _lib():
         L.mbv_synthesize.argtypes = [vp, i32, vp, C.c_float, i32, C.POINTER(MbvOutputs), vp]
         L.mbv_decode.argtypes = [vp, vp, vp, i32, i32, C.POINTER(MbvOutputs), vp]
         L.mbv_stage_times_ms.argtypes = [vp, C.POINTER(C.c_float * 5)]
+        L.mbv_voice_conversion.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MbvOutputs), vp, vp]
         _LIB = L
     return _LIB
 
@@ -71,6 +73,11 @@ def bind(RefSynthesizerTrn):
     class SynthesizerTrn(RefSynthesizerTrn):
         _mbv = None
         _mbv_sig = None
+        _mbv_slots = None
+
+        def refresh_weights(self):
+            """Force a re-fold / re-upload (only needed after edits that bypass the version counters, e.g. through `.data`)."""
+            self._mbv_sig = None
 
         # ---- replaces nothing in the reference: the handle is built on first use -----------------
         def _mbv_handle(self):
@@ -93,18 +100,37 @@ def bind(RefSynthesizerTrn):
                 c.resblock_type = int(self.resblock)
                 c.n_speakers, c.gin_channels = self.n_speakers, self.gin_channels
                 c.use_sdp = int(bool(self.use_sdp))
-                # decoder selection of models.py:634-644
-                c.decoder = 1 if getattr(self, "ms_istft_vits", False) else (0 if getattr(self, "mb_istft_vits", False) else 2)
+                # decoder selection in the order of models.py:634-644 (mb, then ms, then istft_vits; else "Decoder Error")
+                if getattr(self, "mb_istft_vits", False):
+                    c.decoder = 0
+                elif getattr(self, "ms_istft_vits", False):
+                    c.decoder = 1
+                elif getattr(self, "istft_vits", False):
+                    c.decoder = 2
+                else:
+                    raise RuntimeError("Decoder Error in json file")          # models.py:644 prints this and goes on without self.dec
                 c.device = dev.index if dev.index is not None else torch.cuda.current_device()
                 h = C.c_void_p()
                 if L.mbv_create(C.byref(c), C.byref(h)):
                     raise RuntimeError("mbv_create failed: %s" % L.mbv_last_error(None).decode())
                 self._mbv = h
             # replaces load_state_dict as seen by the kernels (utils.py:22-47): hand every key over
-            # whenever the parameters changed (weight-norm is folded inside mbv_finalize_weights)
-            sig = tuple((t.data_ptr(), t._version) for t in self.state_dict().values())
+            # whenever the parameters changed (weight-norm is folded inside mbv_finalize_weights).
+            # Which (module, slot) holds each state-dict key is worked out once; per call only the
+            # storage pointer and version counter of the tensor currently in that slot are compared
+            # (load_state_dict copies in place and bumps _version; .to() / .half() swap the storage).
+            if self._mbv_slots is None:
+                mods = dict(self.named_modules())
+                slots = []
+                for k in self.state_dict().keys():
+                    owner, _, leaf = k.rpartition(".")
+                    m = mods[owner]
+                    slots.append((k, m._parameters if leaf in m._parameters else m._buffers, leaf))
+                self._mbv_slots = slots
+            cur = [(k, d[leaf]) for k, d, leaf in self._mbv_slots]
+            sig = tuple((t.data_ptr(), t._version) for _, t in cur)
             if sig != self._mbv_sig:
-                for k, v in self.state_dict().items():
+                for k, v in cur:
                     a = v.detach().to("cpu", torch.float32).contiguous().numpy()
                     _check(self._mbv, L.mbv_load_weight(self._mbv, k.encode(), a.ctypes.data_as(C.c_void_p),
                                                         (C.c_int64 * a.ndim)(*a.shape), a.ndim), "mbv_load_weight(%s)" % k)
@@ -131,9 +157,8 @@ def bind(RefSynthesizerTrn):
             out.o_mb = o_mb.data_ptr() if o_mb is not None else None
             return o, o_mb, spec, phase
 
-        # ---- replaces SynthesizerTrn.infer (models.py:697-737) --------------------------------------
-        @torch.no_grad()
-        def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., max_len=None):
+        # ---- models.py:697-737 (infer) and :742-788 (infer_z_only) share everything up to the decoder --
+        def _mbv_run(self, x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, max_len, decode):
             h, dev = self._mbv_handle()
             L = _lib()
             x = x.to(dev, torch.int64).contiguous()
@@ -148,27 +173,49 @@ def bind(RefSynthesizerTrn):
                 noise_w = torch.randn(B, 2, T).to(dev) if self.use_sdp else None
                 _check(h, L.mbv_encode(h, _p(x), _p(x_lengths), _p(sid), B, T, float(length_scale), _p(noise_w),
                                        float(noise_scale_w), _p(ylen), st), "mbv_encode")       # models.py:701-719
-                if int(ylen.min()) < 0:                                   # nn.Embedding's IndexError
+                lo, hi = (int(v) for v in torch.stack(torch.aminmax(ylen)).tolist())   # the host sync of commons.py:123
+                if lo < 0:                                                # nn.Embedding's IndexError
                     raise IndexError("index out of range in self")
-                Tp = int(ylen.max())                                      # the host sync of commons.py:123
-                Td = Tp if max_len is None else min(Tp, int(max_len))
+                Tp = hi
                 f32 = dict(device=dev, dtype=torch.float32)
                 out = MbvOutputs()
                 attn, y_mask = torch.empty(B, 1, Tp, T, **f32), torch.empty(B, 1, Tp, **f32)
                 z, z_p, m_p, logs_p = (torch.empty(B, I, Tp, **f32) for _ in range(4))
                 out.attn, out.y_mask = attn.data_ptr(), y_mask.data_ptr()
                 out.z, out.z_p, out.m_p, out.logs_p = z.data_ptr(), z_p.data_ptr(), m_p.data_ptr(), logs_p.data_ptr()
-                o, o_mb, spec, phase = self._mbv_decoder_outputs(B, Td, dev, out)
+                o = o_mb = spec = phase = None
+                Td = 0
+                if decode:
+                    # (z * y_mask)[:, :, :max_len] (models.py:734): a slice, so max_len <= 0 leaves nothing
+                    # to decode — the reference then fails inside its first conv; the library reads
+                    # max_len <= 0 as "no clamp", so it must never see that value from here
+                    Td = Tp if max_len is None else max(0, min(Tp, int(max_len)))
+                    if Td <= 0:
+                        raise ValueError("max_len leaves no frames to decode")
+                    o, o_mb, spec, phase = self._mbv_decoder_outputs(B, Td, dev, out)
                 noise = torch.randn(B, I, Tp, **f32)                      # randn_like(m_p), models.py:729
                 _check(h, L.mbv_synthesize(h, Tp, _p(noise), float(noise_scale), Td if max_len is not None else 0,
                                            C.byref(out), st), "mbv_synthesize")                  # models.py:720-734
                 t5 = (C.c_float * 5)()
                 _check(h, L.mbv_stage_times_ms(h, C.byref(t5)), "mbv_stage_times_ms")             # the timings dict
-            timings = dict(zip(("text_encoder", "duration_predictor", "alignment_and_projection", "flow",
-                                "waveform_decoder"), (v * 1e-3 for v in t5)))
+            names = ("text_encoder", "duration_predictor", "alignment_and_projection", "flow", "waveform_decoder")
+            timings = dict(zip(names if decode else names[:4], (v * 1e-3 for v in t5)))
             return o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings
 
+        # ---- replaces SynthesizerTrn.infer (models.py:697-737) --------------------------------------
+        @torch.no_grad()
+        def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., max_len=None):
+            return self._mbv_run(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, max_len, True)
+
+        # ---- replaces SynthesizerTrn.infer_z_only (models.py:742-788): no decoder launch at all -----
+        @torch.no_grad()
+        def infer_z_only(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1., max_len=None):
+            r = self._mbv_run(x, x_lengths, sid, noise_scale, length_scale, noise_scale_w, None, False)
+            return r[4], r[5], r[6], r[7]
+
         # ---- replaces net.dec(z, g) (models.py:344-377 / 430-467 / 286-300) ------------------------
+        # `model.dec(z, g=g)` callers (synthesis_module.py:158-160, the chunked-decoding notebooks) are
+        # routed here by __init__ below; `model.decode(z, g)` is the same thing by name.
         @torch.no_grad()
         def decode(self, z, g=None):
             h, dev = self._mbv_handle()
@@ -181,6 +228,38 @@ def bind(RefSynthesizerTrn):
                 _check(h, _lib().mbv_decode(h, _p(z), _p(g), B, Tp, C.byref(out),
                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mbv_decode")
             return o, o_mb, spec, phase
+
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            # the decoder module keeps its parameters (state_dict, checkpoints); only its forward moves
+            ref = weakref.ref(self)
+            self.dec.forward = lambda x, g=None: ref().decode(x, g)
+
+        # ---- replaces SynthesizerTrn.voice_conversion (models.py:790-798) ---------------------------
+        @torch.no_grad()
+        def voice_conversion(self, y, y_lengths, sid_src, sid_tgt):
+            assert self.n_speakers > 0, "n_speakers have to be larger than 0."          # models.py:791
+            h, dev = self._mbv_handle()
+            y = y.to(dev, torch.float32).contiguous()
+            B, _, T = y.shape
+            y_lengths, sid_src, sid_tgt = (t.to(dev, torch.int64).contiguous() for t in (y_lengths, sid_src, sid_tgt))
+            I = self.inter_channels
+            f32 = dict(device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                noise = torch.randn(B, I, T, **f32)                       # randn_like(m) of PosteriorEncoder, models.py:245
+                out = MbvOutputs()
+                o, o_mb, spec, phase = self._mbv_decoder_outputs(B, T, dev, out)
+                y_mask = torch.empty(B, 1, T, **f32)
+                z, z_p, z_hat = (torch.empty(B, I, T, **f32) for _ in range(3))
+                out.y_mask, out.z, out.z_p, out.m_p = y_mask.data_ptr(), z.data_ptr(), z_p.data_ptr(), z_hat.data_ptr()
+                status = torch.empty(B, dtype=torch.int32, device=dev)
+                _check(h, _lib().mbv_voice_conversion(h, _p(y), _p(y_lengths), _p(sid_src), _p(sid_tgt), B, T, _p(noise),
+                                                      C.byref(out), _p(status),
+                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "mbv_voice_conversion")
+                if bool(status.any()):
+                    raise IndexError("index out of range in self")       # nn.Embedding's message
+            return o, o_mb, y_mask, (z, z_p, z_hat)
 
     def out_is_single_band(m):
         return not (getattr(m, "ms_istft_vits", False) or getattr(m, "mb_istft_vits", False))

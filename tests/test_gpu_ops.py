@@ -375,8 +375,47 @@ def test_reference_side_binding_runs_against_golden():
         assert rms(o.cpu().numpy() - gold["o"]) < 1e-4, fx
         assert rms(z.cpu().numpy() - gold["z"]) <= 5e-5 * rms(gold["z"]), fx
         assert set(timings) == {"text_encoder", "duration_predictor", "alignment_and_projection", "flow", "waveform_decoder"}
-        do = net.decode(z[:, :, :20].contiguous(), None if sid is None else torch.from_numpy(sd["emb_g.weight"])[gold["sid"]].cuda())[0]
+        g = None if sid is None else torch.from_numpy(sd["emb_g.weight"])[gold["sid"]].cuda()
+        do = net.decode(z[:, :, :20].contiguous(), g)[0]
         assert do.shape == (z.shape[0], 1, 256 * 20) and torch.isfinite(do).all()
+        # `model.dec(z, g=g)` (synthesis_module.py:158-160) is routed to the same entry
+        assert torch.equal(net.dec(z[:, :, :20].contiguous(), g=None if g is None else g.unsqueeze(-1))[0], do)
+        # infer_z_only (models.py:742-788): same latents, four timings, no decoder launch
+        a2, m2, (z2, zp2, mp2, lp2), t2 = net.infer_z_only(
+            torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda(), sid=sid, noise_scale=0, length_scale=1)
+        assert torch.equal(z2, z) and torch.equal(a2, attn) and torch.equal(m2, y_mask) and torch.equal(mp2, m_p)
+        assert set(t2) == {"text_encoder", "duration_predictor", "alignment_and_projection", "flow"}
+        # max_len (models.py:734 slices the decoder input): clamps; <= 0 leaves nothing and must not reach the library as "no clamp"
+        o5 = net.infer(torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda(), sid=sid,
+                       noise_scale=0, length_scale=1, max_len=5)[0]
+        assert o5.shape[-1] == 256 * 5
+        for bad in (0, -3):
+            with pytest.raises(ValueError):
+                net.infer(torch.from_numpy(gold["x"]).cuda(), torch.from_numpy(gold["x_lengths"]).cuda(), sid=sid,
+                          noise_scale=0, length_scale=1, max_len=bad)
+    # voice_conversion (models.py:790-798) through the binding, against the reference's golden
+    gold = load_fixture("vc_uudb_b2")
+    hps, cfg = config_for(FIXTURES["vc_uudb_b2"], int(gold["n_vocab"]))
+    net = Bound(cfg, dict(hps.model), hps.data.n_speakers)
+    sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    y = torch.from_numpy(gold["y"]).cuda()
+    noise, real = torch.from_numpy(gold["noise"]).cuda(), torch.randn      # the posterior encoder's draw, pinned to the golden's
+    torch.randn = lambda *a, **k: noise if tuple(a) == tuple(noise.shape) else real(*a, **k)
+    try:
+        o_hat, o_hat_mb, y_mask, (z, z_p, z_hat) = net.voice_conversion(
+            y, torch.from_numpy(gold["y_lengths"]).cuda(), torch.from_numpy(gold["sid_src"]).cuda(), torch.from_numpy(gold["sid_tgt"]).cuda())
+    finally:
+        torch.randn = real
+    assert np.array_equal(y_mask.cpu().numpy(), gold["y_mask"])
+    assert rms(o_hat.cpu().numpy() - gold["o"]) < 1e-4
+    assert rms(z_hat.cpu().numpy() - gold["z_hat"]) <= 5e-5 * rms(gold["z_hat"])
+    with pytest.raises(IndexError):
+        net.voice_conversion(y, torch.from_numpy(gold["y_lengths"]).cuda(), torch.tensor([3, 12]).cuda(), torch.tensor([0, 1]).cuda())
+    # both flags set: the reference's order (models.py:634-644) builds the multiband decoder
+    both = Bound(cfg, dict(hps.model, mb_istft_vits=True, ms_istft_vits=True), hps.data.n_speakers)
+    assert both.mb_istft_vits and both.ms_istft_vits
 
 
 @pytest.mark.timeout(600)

@@ -240,3 +240,53 @@ def test_wire_framing_matches_the_service_wrapper():
     with _pt.raises(ValueError):
         wire.frame_pcm16(pcm.astype(np.float32), 24000)
     assert wire.frame_pcm16(torch.from_numpy(pcm[:960]), 24000) == R.frame_pcm16(pcm[:960], 24000)
+
+
+def test_reference_binding_binds_the_real_reference_class():
+    """`reference_binding.bind` over the REAL `/root/reference/models.SynthesizerTrn` (build container only —
+    the reference does not travel to the GPU box, where this test skips): construct through the reference's
+    own ctor and hparams, strict `load_state_dict` of the synthetic checkpoint, every inference entry point of
+    the class is the binding's, `model.dec` is routed, and with no GPU the calls raise instead of falling
+    back to the reference's eager CPU modules.  Runs in a child process: importing the reference needs
+    `sys.modules` stubs and a `.cuda()` no-op (tests/golden/make_golden.py) that must not leak into this one."""
+    import subprocess
+    import sys
+    ref = os.environ.get("MBV_REFERENCE", "/root/reference")
+    if not os.path.isfile(os.path.join(ref, "models.py")):
+        pytest.skip("reference checkout not present (GPU box)")
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests", "golden"))
+import torch
+import make_golden
+models, utils, stft, pqmf = make_golden.import_reference()
+from mb_istft_vits_amd import synth, spec
+from mb_istft_vits_amd.reference_binding import bind
+Bound = bind(models.SynthesizerTrn)
+assert Bound.__name__ == "SynthesizerTrn" and issubclass(Bound, models.SynthesizerTrn)
+for name in ("infer", "infer_z_only", "voice_conversion", "decode"):
+    assert name in Bound.__dict__, name
+for cfg_name in ("ljs_mini_mb_istft_vits", "uudb_ms_istft_vits_ms"):
+    hps = utils.get_hparams_from_file(os.path.join(make_golden.REF, "configs", cfg_name + ".json"))
+    net = Bound(59, hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
+                n_speakers=hps.data.n_speakers, **hps.model).eval()
+    cfg = spec.config_from_ctor(59, hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
+                                n_speakers=hps.data.n_speakers, **hps.model)
+    sd = synth.make_state_dict(cfg, 1234)
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not missing and not unexpected
+    x, xl = torch.randint(1, 59, (2, 9)), torch.tensor([9, 7])
+    sid = torch.tensor([0, 1]) if hps.data.n_speakers else None
+    for call in (lambda: net.infer(x, xl, sid=sid, noise_scale=0), lambda: net.infer_z_only(x, xl, sid=sid),
+                 lambda: net.dec(torch.zeros(1, hps.model["inter_channels"], 8)),
+                 lambda: net.decode(torch.zeros(1, hps.model["inter_channels"], 8))):
+        try:
+            call()
+        except RuntimeError as e:
+            assert "no CPU path" in str(e), e
+        else:
+            raise AssertionError("a CPU call went through: the binding fell back to the reference's modules")
+print("BOUND-OK")
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BOUND-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
