@@ -999,11 +999,51 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   // (6 accumulators per wave), double-buffered LDS.  Otherwise 256-thread, 128 x 128 tile.
   static const int mode = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
   bool big = false;
+  int nb_big = 0;                          // r03: > 0: the first nb_big utterances on the 512-thread shape, the rest on the 256-thread one
   if (wide_m && mode >= 3 && a.T >= 384) {
     const double eff2 = 0.90 * a.T / (double)(((a.T + 127) / 128) * 128);
     const double eff3 = a.T / (double)(((a.T + 383) / 384) * 384);
-    const long blocks3 = (long)((a.T + 383) / 384) * ((a.M + 127) / 128) * a.B;
+    const long tpb3 = (long)((a.T + 383) / 384) * ((a.M + 127) / 128);          // tiles per utterance, 128 x 384
+    const long tpb2 = (long)((a.T + 127) / 128) * ((a.M + 127) / 128);          // ... 128 x 128
+    const long blocks3 = tpb3 * a.B;
     big = eff3 >= eff2 && blocks3 >= 512;
+    // Launches between one and two rounds of 128 x 384 tiles (the per-GPU shares of the sharded configurations:
+    // uudb B = 32 has 384 tiles for its 256-channel convs) quantise badly on either shape: 1.5 rounds of big
+    // tiles run as 2, 2.25 rounds of small ones as 3.  Both shapes compute an output element with the same
+    // chain of operations, so the batch can be cut between them: whole rounds of big tiles (one per CU) for the
+    // first utterances, the rest as 128 x 128 tiles on the 512 half-CU slots.  In units of one big tile's time
+    // (a small tile on half a CU: 1/3 of the work on 1/2 of the waves, measured 0.63 - 0.65):
+    static const int split_on = [] { const char* e = getenv("MBV_CONV_BATCH_SPLIT"); return e ? atoi(e) : 1; }();
+    if (split_on && !a.splitk && eff3 >= eff2 && blocks3 > 256 && a.B > 1) {
+      const double c2 = 0.65;
+      auto rounds = [](long n, long slots) { return (double)((n + slots - 1) / slots); };
+      double best = big ? rounds(blocks3, 256) : rounds(tpb2 * a.B, 512) * c2;
+      for (long k = blocks3 / 256; k >= 1; --k) {
+        const long nb = 256 * k / tpb3;                                          // utterances that fill k rounds (or just under)
+        if (nb < 1 || nb >= a.B) continue;
+        const double cost = rounds(nb * tpb3, 256) + rounds((a.B - nb) * tpb2, 512) * c2;
+        if (cost < 0.9 * best) { best = cost / 0.9; nb_big = (int)nb; }      // (predicted gains below ~10 % did not materialise: B = 96 measured +4 %)
+      }
+    }
+  }
+  if (nb_big > 0) {
+    ConvArgs a1 = a, a2 = a;
+    const int nb = nb_big;
+    a1.B = nb;
+    a2.B = a.B - nb;
+    a2.x += (int64_t)nb * a.x_bstride;
+    a2.y += (int64_t)nb * a.y_bstride;
+    if (a.in_lens) a2.in_lens += nb;
+    if (a.out_lens) a2.out_lens += nb;
+    if (a.chan_add) a2.chan_add += (int64_t)nb * a.Cin;
+    if (a.res) a2.res += (int64_t)nb * a.res_bstride;
+    if (a.res_chan_add) a2.res_chan_add += (int64_t)nb * a.M;
+    if (a.accum_in) a2.accum_in += (int64_t)nb * a.y_bstride;
+    if (a.gate_cond) a2.gate_cond += (int64_t)nb * a.gate_cond_bstride;
+    if (a.skip) a2.skip += (int64_t)nb * (a.M - a.split) * a.T;
+    launch_ck<2, 3, 4>(a1, s);
+    launch_ck<2, 2, 2>(a2, s);
+    return;
   }
   if (wide_m) {
     if (big) launch_ck<2, 3, 4>(a, s);

@@ -395,7 +395,7 @@ def test_reference_side_binding_runs_against_golden():
                           noise_scale=0, length_scale=1, max_len=bad)
     # voice_conversion (models.py:790-798) through the binding, against the reference's golden
     gold = load_fixture("vc_uudb_b2")
-    hps, cfg = config_for(FIXTURES["vc_uudb_b2"], int(gold["n_vocab"]))
+    hps, cfg = config_for("uudb_ms_istft_vits_ms", int(gold["n_vocab"]))
     net = Bound(cfg, dict(hps.model), hps.data.n_speakers)
     sd = synth.make_state_dict(cfg, int(gold["weight_seed"]))
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
