@@ -171,48 +171,76 @@ def main():
                                 n_speakers=hps.data.n_speakers, **hps.model)
     cfg = net.cfg
     sr = hps.data.sampling_rate
-    # ---- weights: rank 0 generates, RCCL broadcast to the rest -----------------
-    sd_np = synth.make_state_dict(cfg, 1234) if rank == 0 else None
-    if dist_on:
-        shapes = mspec.param_shapes(cfg)
-        sd = mdist.broadcast_state_dict(
-            {k: torch.from_numpy(v) for k, v in sd_np.items()} if rank == 0 else None, shapes, dev)
-        net.load_state_dict(sd)
-    else:
-        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    # ---- weights: rank 0 generates the checkpoint, folds and packs it once; the FOLDED arena is broadcast over
+    # RCCL and imported by the other ranks (no state dict, no host-side fold, no upload there)
+    if rank == 0:
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, 1234).items()})
     net = net.to(dev).eval()
+    arena_floats, t_arena = None, None
+    if dist_on:
+        torch.cuda.synchronize(dev)
+        t_a = time.perf_counter()
+        arena_floats = mdist.broadcast_arena(net, src=0)
+        torch.cuda.synchronize(dev)
+        t_arena = time.perf_counter() - t_a
 
     B = args.batch
     x_np, xl_np, sid_np = synth.synthetic_batch(cfg, B * world, args.t_text, seed=0, ragged=args.ragged)
     x, xl = torch.from_numpy(x_np).to(dev), torch.from_numpy(xl_np).to(dev)
     sid = torch.from_numpy(sid_np).to(dev) if sid_np is not None else None
 
+    # N > 1: the all-gathers of step k run on a side stream under the kernels of step k + 1 (`overlap="next"`: the
+    # call returns a handle, its tensors are taken one step later); MBV_BENCH_OVERLAP=none|halves for A/B
+    overlap = os.environ.get("MBV_BENCH_OVERLAP", "next")
+    overlap = None if overlap in ("", "none") else overlap
+    pending = []
+
     def step(outputs=None):
         # outputs=None: every shard / the single GPU materialises all 8 tensors of the reference tuple
         if dist_on:
-            o, ylen = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1, outputs=outputs)
+            r = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1, outputs=outputs, overlap=overlap)
+            if isinstance(r, mdist.Gathered):
+                pending.append(r)
+                if len(pending) > 1:
+                    return pending.pop(0).result()       # the step before this one: its gather has had a whole step
+                return None, None
+            o, ylen = r
         else:
             (o, *_), ylen = net.infer_with_lengths(x, xl, sid, noise_scale=0, length_scale=1, outputs=outputs)
         return o, ylen
+
+    def drain():
+        r = (None, None)
+        while pending:
+            r = pending.pop(0).result()
+        return r
+
+    def run_steps(n, outputs=None):
+        """n steps back to back, every gather waited for at the end; -> the last step's (o, y_lengths)"""
+        last = (None, None)
+        for _ in range(n):
+            r = step(outputs)
+            if r[0] is not None:
+                last = r
+        r = drain()
+        return r if r[0] is not None else last
 
     def sync():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        o, ylen = step()
+    run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):                  # exactly K steps, no host sync inside beyond infer's own
-        o, ylen = step()
-    sync()
+    o, ylen = run_steps(args.steps)              # exactly K steps, no host sync inside beyond infer's own; the last
+    sync()                                       # step's gather is waited for inside the timed region
     elapsed = time.perf_counter() - t0
     # kernel-level timers for the roofline lines: a separate, untimed pass (reading the HIP events
     # synchronises the stream, which does not belong inside the timed region)
     conv_ms, istft_ms = [], []
     for _ in range(min(args.steps, 10)):
-        step()
+        run_steps(1)
         c, i = net.kernel_times_ms()             # HIP events on the launch stream
         conv_ms.append(c)
         istft_ms.append(i)
@@ -227,13 +255,11 @@ def main():
 
     # secondary: the same job when the caller only takes the waveform (`outputs=("o",)`, what
     # tts_vits.py:134-137 uses of the tuple) — not the headline
-    for _ in range(2):
-        step(("o",))
+    run_steps(2, ("o",))
     sync()
     t1 = time.perf_counter()
     n_wave = max(3, args.steps // 2)
-    for _ in range(n_wave):
-        step(("o",))
+    run_steps(n_wave, ("o",))
     sync()
     wave_elapsed = time.perf_counter() - t1
     if dist_on:
@@ -246,19 +272,16 @@ def main():
     o_exact = o.clone()
     net.set_option("conv_bf16", 3)
     try:
-        for _ in range(2):
-            o3, _ = step()
+        run_steps(2)
         sync()
         t2 = time.perf_counter()
-        for _ in range(n_wave):
-            o3, _ = step()
+        o3, _ = run_steps(n_wave)
         sync()
         bf16_elapsed = time.perf_counter() - t2
         bf16_rms = float((o3.double() - o_exact.double()).pow(2).mean().sqrt())
     finally:
         net.set_option("conv_bf16", 0)
-    for _ in range(2):                           # back on the exact path before the per-stage timers below are read
-        step()
+    run_steps(2)                                 # back on the exact path before the per-stage timers below are read
     sync()
     if dist_on:
         t = torch.tensor([bf16_elapsed], device=dev, dtype=torch.float64)
@@ -269,9 +292,31 @@ def main():
     if dist_on:
         names = [None] * world
         dist.all_gather_object(names, "rank %d: cuda:%d %s" % (rank, dev_index, torch.cuda.get_device_name(dev)))
+        # where a step's time goes, from HIP events on the streams the work was issued on (untimed pass; MAX over
+        # ranks): the plain schedule (gathers on the caller's stream) gives each collective's own time, the
+        # overlapped one what is left exposed
+        def timed(ov, n=4):
+            acc = None
+            for _ in range(n):
+                tm = mdist.StepTimes()
+                r = mdist.sharded_infer(net, x, xl, sid, noise_scale=0, length_scale=1, outputs=None, overlap=ov, timing=tm)
+                if isinstance(r, mdist.Gathered):
+                    r.result()
+                torch.cuda.synchronize(dev)
+                d = tm.ms()
+                acc = d if acc is None else {k: (acc[k] + v if isinstance(v, float) else v) for k, v in d.items()}
+            vals = torch.tensor([acc[k] / n for k in sorted(acc) if isinstance(acc[k], float)], device=dev, dtype=torch.float64)
+            dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            return {k: round(float(v), 4) for k, v in zip([k for k in sorted(acc) if isinstance(acc[k], float)], vals.tolist())}
+        timing_ms = {"plain": timed(None)}
+        if overlap:
+            timing_ms[overlap] = timed(overlap)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": names,
-                     "rehearsal": bool(share), "collectives_per_step":
-                     "1 all_reduce(MAX) of [T', status] (2 x int64) + all_gather(waveform rows) + all_gather(y_lengths)"}
+                     "rehearsal": bool(share), "overlap": overlap, "collectives_per_step":
+                     "1 all_reduce(MAX) of [T', status] (2 x int64) + all_gather(waveform rows) + all_gather(y_lengths)",
+                     "timing_ms": timing_ms,
+                     "weights": {"what": "rank 0 folds once, broadcast of the folded arena, mbv_import_arena on the others",
+                                 "arena_mb": round(arena_floats * 4 / 1e6, 1), "broadcast_and_import_s": round(t_arena, 3)}}
 
     stage_ms = None
     if rank == 0:
@@ -345,6 +390,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_infer
         nb = min(8, B)
+        sd_np = synth.make_state_dict(cfg, 1234)
         W = ref_infer.Weights(sd_np)
         sid8 = sid_np[:nb] if sid_np is not None else None
 

@@ -100,6 +100,18 @@ const char *mbv_last_error(const mbv_model *m);
 int mbv_load_weight(mbv_model *m, const char *name, const float *data,
                     const int64_t *shape, int ndim);
 int mbv_finalize_weights(mbv_model *m, void *stream);
+
+/* ---- the folded weight arena across processes (no reference counterpart; SURVEY §8e: "RCCL broadcast of the
+ * folded weight arena from rank 0").  One rank loads the checkpoint and finalizes; the others receive the arena
+ * over the collective of their choice (device buffers) and import it: its layout is a function of mbv_config
+ * alone, so no state dict, no host-side weight-norm fold and no host->device upload happens on the receivers.
+ *   mbv_arena_floats   size of the finalized arena in floats (-1: not finalized)
+ *   mbv_export_arena   device-to-device copy of it into dst (capacity in floats)
+ *   mbv_import_arena   lay the arena out and fill it from src (device); n_floats must equal the exporter's
+ *                      mbv_arena_floats (same configuration, same library build), else the call fails */
+int64_t mbv_arena_floats(mbv_model *m);
+int mbv_export_arena(mbv_model *m, float *dst, int64_t capacity, void *stream);
+int mbv_import_arena(mbv_model *m, const float *src, int64_t n_floats, void *stream);
 /* Number of state-dict keys still missing before finalize can succeed;
  * writes up to `cap` bytes of a comma-separated list into `buf` if non-NULL. */
 int mbv_missing_weights(mbv_model *m, char *buf, size_t cap);

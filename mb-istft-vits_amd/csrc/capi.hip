@@ -51,6 +51,9 @@ struct mbv_model {
   std::map<std::string, HostTensor> raw;
   std::map<std::string, std::vector<int64_t>> expected;   // key -> shape
   bool finalized = false;
+  size_t arena_used = 0;           // floats of the packed arena in use (darena may be larger after a reload)
+  int64_t import_n = 0;
+  const float* import_src = nullptr;   // do_finalize: lay the arena out from the config alone and fill it from this device buffer (mbv_import_arena)
 
   // weight arena
   std::vector<float> harena;
@@ -374,6 +377,7 @@ struct Packer {
     const HostTensor& g = t(prefix + ".weight_g");
     const int64_t d0 = v.shape[0], inner = v.numel() / d0;
     std::vector<float> w(v.data.size());
+    if (m->import_src) return w;                   // layout-only pass: the contents come from the imported arena
     for (int64_t i = 0; i < d0; ++i) {
       double n2 = 0;
       for (int64_t j = 0; j < inner; ++j) { const double x = v.data[i * inner + j]; n2 += x * x; }
@@ -537,6 +541,15 @@ std::vector<float> synthesis_table(const float* h63) {
 }
 
 int do_finalize(mbv_model* m, hipStream_t stream) {
+  if (m->import_src) {                 // zero tensors of the expected shapes stand in for the checkpoint
+    m->raw.clear();
+    for (auto& kv : m->expected) {
+      HostTensor t;
+      t.shape = kv.second;
+      t.data.assign((size_t)t.numel(), 0.f);
+      m->raw[kv.first] = std::move(t);
+    }
+  }
   for (auto& kv : m->expected)
     if (!m->raw.count(kv.first)) return m->fail("missing weight '%s'", kv.first.c_str());
   const mbv_config& c = m->cfg;
@@ -777,9 +790,18 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
     HIPCHK(m, hipMalloc((void**)&m->darena, arena.size() * sizeof(float)));
     m->darena_floats = arena.size();
   }
-  HIPCHK(m, hipMemcpyAsync(m->darena, arena.data(), arena.size() * sizeof(float),
-                           hipMemcpyHostToDevice, stream));
+  if (m->import_src) {
+    if ((int64_t)arena.size() != m->import_n)
+      return m->fail("mbv_import_arena: %lld floats offered, this configuration's arena has %zu (exported by another configuration or library build?)",
+                     (long long)m->import_n, arena.size());
+    HIPCHK(m, hipMemcpyAsync(m->darena, m->import_src, arena.size() * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    m->raw.clear();
+  } else {
+    HIPCHK(m, hipMemcpyAsync(m->darena, arena.data(), arena.size() * sizeof(float),
+                             hipMemcpyHostToDevice, stream));
+  }
   HIPCHK(m, hipStreamSynchronize(stream));
+  m->arena_used = arena.size();
   m->harena.swap(arena);
   m->finalized = true;
   m->split_valid = false;
@@ -1303,6 +1325,36 @@ int mbv_finalize_weights(mbv_model* m, void* stream) {
   if (!m) return 1;
   DEVICE_GUARD(m);
   return do_finalize(m, (hipStream_t)stream);
+}
+
+int64_t mbv_arena_floats(mbv_model* m) {
+  if (!m) return -1;
+  if (!m->finalized) { m->fail("weights not finalized"); return -1; }
+  return (int64_t)m->arena_used;
+}
+
+int mbv_export_arena(mbv_model* m, float* dst, int64_t capacity, void* stream) {
+  if (!m) return 1;
+  if (!m->finalized) return m->fail("weights not finalized");
+  if (!dst || capacity < (int64_t)m->arena_used) return m->fail("mbv_export_arena: destination holds %lld floats, the arena %zu", (long long)capacity, m->arena_used);
+  DEVICE_GUARD(m);
+  HIPCHK(m, hipMemcpyAsync(dst, m->darena, m->arena_used * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int mbv_import_arena(mbv_model* m, const float* src, int64_t n_floats, void* stream) {
+  if (!m) return 1;
+  if (!src || n_floats <= 0) return m->fail("mbv_import_arena: bad arguments");
+  DEVICE_GUARD(m);
+  // the arena's layout is a function of the configuration alone (every offset comes from a tensor SHAPE): the same
+  // packing pass runs over zero tensors, skipping the weight-norm folds, and the contents arrive from `src`
+  m->import_src = src;
+  m->import_n = n_floats;
+  m->finalized = false;
+  const int rc = do_finalize(m, (hipStream_t)stream);
+  m->import_src = nullptr;
+  if (rc) m->raw.clear();
+  return rc;
 }
 
 int mbv_speaker_embedding(mbv_model* m, const int64_t* sid, int B, float* out, void* stream) {

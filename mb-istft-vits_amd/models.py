@@ -224,6 +224,38 @@ class SynthesizerTrn(nn.Module):
         _capi.check(self._handle, L.mbv_finalize_weights(self._handle, self._stream()),
                     "mbv_finalize_weights")
 
+    def export_arena(self):
+        """The folded, packed weight arena of this model as one flat fp32 device tensor (`mbv_export_arena`):
+        what rank 0 broadcasts in a sharded run instead of the state dict (dist.broadcast_arena)."""
+        h = self._ensure_handle()
+        L = _capi.lib()
+        n = int(L.mbv_arena_floats(h))
+        if n <= 0:
+            raise _capi.MbvError(L.mbv_last_error(h).decode())
+        dev = self._device()
+        flat = torch.empty(n, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _capi.check(h, L.mbv_export_arena(h, self._ptr(flat), n, self._stream()), "mbv_export_arena")
+        return flat
+
+    def import_arena(self, flat):
+        """Take the weights from another process's `export_arena()` (same configuration, same library build):
+        no state dict, no host-side weight-norm fold, no upload.  The module's own parameters keep whatever
+        they held (the synthetic init) and are NOT what the kernels use afterwards; a later `load_state_dict`
+        replaces the imported weights again."""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("move the model to a ROCm device first (.to('cuda')): the arena lives on the GPU")
+        flat = flat.to(device=dev, dtype=torch.float32).contiguous()
+        self._synced_sig = self._weights_signature()      # _ensure_handle: nothing to upload
+        h = self._ensure_handle()
+        with torch.cuda.device(dev):
+            try:
+                _capi.check(h, _capi.lib().mbv_import_arena(h, self._ptr(flat), flat.numel(), self._stream()), "mbv_import_arena")
+            except Exception:
+                self._synced_sig = None
+                raise
+
     def refresh_weights(self):
         """Force a re-fold/re-upload (only needed after in-place edits through `.data`)."""
         self._synced_sig = None
@@ -327,9 +359,14 @@ class SynthesizerTrn(nn.Module):
             if frames_hook is not None:
                 Tp = int(frames_hook(Tp))
             # the reference draws randn_like(m_p) even at noise_scale == 0 (models.py:729)
-            if prior_rows is not None and float(noise_scale) != 0.0:
+            if prior_rows is not None:
+                # sharded run: the draw of the WHOLE batch, this shard's rows — also at noise_scale == 0, so that
+                # the device generator advances exactly as in a single-process run of the full batch (a later
+                # noisy call in the same process then still reproduces the single-process draws).  Cost: the
+                # RNG kernel over B_global x I x T' (222 MB at 8 x 64 utterances, ~0.1 ms) per call.
                 r_lo, r_hi, b_all = prior_rows
-                noise = torch.randn(b_all, I, Tp, device=dev, dtype=torch.float32)[r_lo:r_hi].contiguous()
+                noise = torch.randn(b_all, I, Tp, device=dev, dtype=torch.float32)[r_lo:r_hi]
+                noise = noise.contiguous() if float(noise_scale) != 0.0 else None
             else:
                 noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)
             f32 = dict(device=dev, dtype=torch.float32)
@@ -428,6 +465,26 @@ class SynthesizerTrn(nn.Module):
             _capi.check(h, _capi.lib().mbv_decode(h, self._ptr(z), self._ptr(g), B, Tp, C.byref(out),
                                                   self._stream()), "mbv_decode")
         return o, o_mb, spec, phase
+
+    @torch.no_grad()
+    def _decode_into(self, z, g, outs):
+        """`net.dec` on a block of rows, writing into caller-owned (o, o_mb, spec, phase) — any may be None.
+        dist.sharded_infer(overlap="halves") decodes a shard in two pieces with it."""
+        h = self._ensure_handle()
+        dev = self._device()
+        z = z.to(device=dev, dtype=torch.float32).contiguous()
+        B, _, Tp = z.shape
+        if g is not None:
+            g = g.to(device=dev, dtype=torch.float32).reshape(B, self.cfg.gin_channels).contiguous()
+        out = _capi.MbvOutputs()
+        for name, t in zip(("o", "o_mb", "spec", "phase"), outs):
+            if t is not None:
+                if not t.is_contiguous() or t.shape[0] != B:
+                    raise ValueError("%s: a contiguous block of %d rows expected" % (name, B))
+                setattr(out, name, t.data_ptr())
+        with torch.cuda.device(dev):
+            _capi.check(h, _capi.lib().mbv_decode(h, self._ptr(z), self._ptr(g), B, Tp, C.byref(out),
+                                                  self._stream()), "mbv_decode")
 
     @torch.no_grad()
     def istft_finalize(self, spec, phase):

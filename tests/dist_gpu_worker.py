@@ -27,12 +27,18 @@ def main():
         for name, cfg_name, B, T in (("mini_b5", "ljs_mini_mb_istft_vits", 5, 23),
                                      ("uudb_b5", "uudb_ms_istft_vits_ms", 5, 17),
                                      ("mini_b4", "ljs_mini_mb_istft_vits", 4, 31)):
-            net, sd = make_net(cfg_name, seed=1300)
-            # weights: rank 0's checkpoint through the broadcast entry (the other ranks load what arrives)
-            shapes = mspec.param_shapes(net.cfg)
-            got = mdist.broadcast_state_dict({k: torch.from_numpy(v) for k, v in sd.items()} if rank == 0 else None,
-                                             shapes, dev)
-            net.load_state_dict(got)
+            if name == "uudb_b5":
+                # weights: rank 0's raw checkpoint through the state-dict broadcast (the other ranks load what arrives)
+                net, sd = make_net(cfg_name, seed=1300)
+                shapes = mspec.param_shapes(net.cfg)
+                got = mdist.broadcast_state_dict({k: torch.from_numpy(v) for k, v in sd.items()} if rank == 0 else None,
+                                                 shapes, dev)
+                net.load_state_dict(got)
+            else:
+                # weights: rank 0 loads + folds, the others import the folded arena (never see a state dict:
+                # their module parameters keep another seed's values, which the kernels must not use)
+                net, sd = make_net(cfg_name, seed=1300 if rank == 0 else 7)
+                res[name + "_arena_floats"] = mdist.broadcast_arena(net, src=0)
             x, xl, sid = synth.synthetic_batch(net.cfg, B, T, seed=40 + B, ragged=True)
             xg, xlg = torch.from_numpy(x).to(dev), torch.from_numpy(xl).to(dev)
             sidg = torch.from_numpy(sid).to(dev) if sid is not None else None
@@ -65,6 +71,31 @@ def main():
                 # the group is still usable afterwards
                 o2, _ = mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1)
                 res["after_errors_equal"] = bool(torch.equal(o2, o))
+                # gathers on a side stream: handle now, tensors at result(); and the decoder in two halves with the
+                # first half's rows travelling under the second half's decode — both bitwise the plain call
+                tm = mdist.StepTimes()
+                h = mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1, overlap="next", timing=tm)
+                o3, y3 = h.result()
+                torch.cuda.synchronize()
+                res["overlap_next_equal"] = bool(torch.equal(o3, o) and torch.equal(y3, ylen))
+                res["timing_next"] = tm.ms()
+                tm = mdist.StepTimes()
+                o4, y4 = mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1, overlap="halves", timing=tm,
+                                             outputs=None)
+                torch.cuda.synchronize()
+                res["overlap_halves_equal"] = bool(torch.equal(o4, o) and torch.equal(y4, ylen))
+                res["timing_halves"] = tm.ms()
+                tm = mdist.StepTimes()
+                mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1, timing=tm)
+                torch.cuda.synchronize()
+                res["timing_plain"] = tm.ms()
+                # a quiet call (noise_scale 0) between the seed and a noisy call: the generator must have advanced as
+                # in a single process, so the noisy call still reproduces the single-process draw
+                torch.manual_seed(78)
+                torch.cuda.manual_seed(78)
+                mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1)
+                o_n2, _ = mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0.6, length_scale=1)
+                res["mini_b5_noise_after_quiet"] = {"o": o_n2.cpu()}
         import ctypes as C
         loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "libmbistft_vits.so" in ln]
         res["native_loaded"] = bool(loaded)

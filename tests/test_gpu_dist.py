@@ -54,6 +54,12 @@ def test_two_rank_hip_sharded_infer_equals_full_batch(tmp_path):
     for r in res:
         assert r["bad_token"] == "IndexError" and r["small_batch"] == "ValueError"
         assert r["after_errors_equal"] and r["mini_b5_all_outputs_equal"]
+        assert r["overlap_next_equal"] and r["overlap_halves_equal"]
+        assert r["mini_b5_arena_floats"] == res[0]["mini_b5_arena_floats"] > 0
+        for k in ("timing_plain", "timing_next", "timing_halves"):
+            t = r[k]
+            assert t["world_size"] == world and t["total_ms"] > 0 and t["all_reduce_ms"] >= 0 and t["gather_o_ms"] > 0, (k, t)
+            assert t["overlap"] == (k != "timing_plain")
 
     # single-process full-batch reference on the same device, same kernels
     for name, cfg_name, B, T in (("mini_b5", "ljs_mini_mb_istft_vits", 5, 23),
@@ -80,6 +86,14 @@ def test_two_rank_hip_sharded_infer_equals_full_batch(tmp_path):
             else:
                 assert torch.equal(res[0]["mini_b5_noise"]["o"], o_n.cpu())
             assert not torch.equal(o_n, o)
+            # generator advance at noise_scale == 0: quiet call, then noisy call == single process doing the same
+            torch.manual_seed(78)
+            torch.cuda.manual_seed(78)
+            net.infer(xg, xlg, sidg, noise_scale=0, length_scale=1)
+            o_n2 = net.infer(xg, xlg, sidg, noise_scale=0.6, length_scale=1)[0]
+            if os.environ.get("MBV_CONV_SPLITK", "0") in ("", "0"):
+                assert torch.equal(res[0]["mini_b5_noise_after_quiet"]["o"], o_n2.cpu())
+                assert torch.equal(res[1]["mini_b5_noise_after_quiet"]["o"], o_n2.cpu())
 
 
 @pytest.mark.timeout(900)
