@@ -267,6 +267,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wave_elapsed = float(t.item())
 
+    # ragged batches only: the OPT-IN trimmed decode (infer(outputs=("o",), trim=True): per utterance only what its valid
+    # samples depend on is computed; those samples are bitwise the default's) — not the headline
+    trim_info = None
+    if args.ragged and not dist_on and cfg.decoder != mspec.DEC_SB:
+        def tstep():
+            return net.infer(x, xl, sid, noise_scale=0, length_scale=1, outputs=("o",), trim=True)[0]
+        for _ in range(2):
+            o_t = tstep()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(n_wave):
+            o_t = tstep()
+        sync()
+        trim_elapsed = time.perf_counter() - t3
+        n_valid = [int(v) * cfg.samples_per_frame for v in ylen.tolist()]
+        same = all(bool(torch.equal(o_t[b, 0, :n], o[b, 0, :n])) for b, n in enumerate(n_valid))
+        trim_info = {"what": "OPT-IN infer(outputs=('o',), trim=True) on this ragged batch: decoder / iSTFT tiles behind "
+                             "y_lengths[b] + 32 frames are not computed; valid samples bitwise the default's",
+                     "value": round(valid_samples * n_wave / trim_elapsed, 1), "ms_per_step": round(trim_elapsed / n_wave * 1e3, 3),
+                     "valid_samples_bitwise_equal_to_default": same,
+                     "padded_frame_share": round(1.0 - float(ylen.sum()) / (len(n_valid) * (o.shape[-1] // cfg.samples_per_frame)), 4)}
+
     # tertiary: the OPT-IN split-bf16 conv mode (conv_bf16 = 3; not IEEE fp32 multiplication, so never the
     # headline): same job, all outputs, plus its waveform's distance from the exact mode's
     o_exact = o.clone()
@@ -458,6 +480,7 @@ def main():
                           "value": round(valid_samples * n_wave / bf16_elapsed, 1),
                           "ms_per_step": round(bf16_elapsed / n_wave * 1e3, 3),
                           "waveform_rms_vs_exact_mode": bf16_rms, "bar": 1e-4},
+            "trim": trim_info,
             "dist": dist_info,
             "stage_ms": stage_ms, "roofline": roof, "roofline_conv": roof_conv, "roofline_other": roof_other,
             "cpu_baseline": cpu,

@@ -169,6 +169,14 @@ int mbv_speaker_embedding(mbv_model *m, const int64_t *sid, int B, float *out, v
  *                  chip (single utterances, small batches) the stage's three ResBlocks (models.py:353-359)
  *                  run on three internal streams forked from / joined to `stream`; bitwise the result of
  *                  the one-stream schedule (0).
+ *   "trim"         0 (default).  1: OPT-IN trimmed decode for ragged batches whose caller takes only the waveform
+ *                  and cuts it by y_lengths (tts_vits.py:134-137 takes [0][0,0] of one utterance): in mbv_synthesize
+ *                  the decoder computes, per utterance, only the tiles that hold frames below y_lengths[b] + 32
+ *                  (its one-sided receptive field is 25 z-frames) and the fused iSTFT stops at 256 y_lengths[b]
+ *                  samples.  Valid samples are bitwise those of the default; the padded region of `o` — defined
+ *                  output of the reference, computed by the default — is left as the caller allocated it
+ *                  (the Python shim zero-fills it).  Requires o_mb / spec / phase NULL; multiband / multistream
+ *                  decoders, not the low-latency mode.  Never the headline configuration.
  *   "conv_bf16"    0 (default; MBV_CONV_BF16): every contraction in exact fp32.  3: OPT-IN split-bf16
  *                  arithmetic in the large conv launches (the decoder's ResBlock convs of a batch): each
  *                  fp32 operand is split into bf16(x) and bf16(x - bf16(x)), the three leading products

@@ -98,6 +98,7 @@ struct mbv_model {
   int xpost_F = 1;             // frames per row of the last x_post stage tensor
   int xpost_rows = 72;         // 72 (4 bands x 18) or 18 (single band)
   int exact_math = 0;          // MBV_ISTFT_EXACT=1: libm transcendentals in the iSTFT kernel
+  int trim = 0;                    // option "trim": opt-in trimmed decode (run_decoder)
   int64_t xpost_chunk_bytes = 0;   // option "xpost_chunk_bytes": sub-batch cap of conv_post + iSTFT (0: 2 GiB - 1)
 
   // state of the last encode
@@ -852,7 +853,7 @@ size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td);
 // frames) is at most 192 tiles of 128 x 384, i.e. cannot fill the chip by itself.
 bool decoder_stage_concurrent(const mbv_model* m, int B, int ch, int Lo) {
   const long conv_tiles = (long)B * ((Lo + 383) / 384) * ((ch + 127) / 128);
-  return m->dec_streams && m->aux_ok && m->cfg.resblock_type != 2 && conv_tiles <= 192;
+  return m->dec_streams && m->aux_ok && m->cfg.resblock_type != 2 && conv_tiles <= 192 && !m->trim;   // (trim: its tile maps are built on the caller's stream)
 }
 
 int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, const float* gvec,
@@ -863,10 +864,32 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
   if (sc.off + decoder_scratch_bytes(c, B, Td) > sc.cap) return m->fail("internal error: decoder scratch arena undersized");
   float* x0 = sc.take<float>((size_t)B * C0 * Td);
   HIPCHK(m, hipEventRecord(m->evk[0], s));
+  // Opt-in trimmed decode (option "trim"; the caller takes only `o` and trims by y_lengths): a conv computes the
+  // column tiles that hold frames below (len_b + kTrimMargin) * rate of its utterance and nothing behind them.  The
+  // decoder's one-sided receptive field is 25.2 z-frames (conv_pre 3 + ups 2 + 0.5, the k = 11 ResBlocks 15 + 3.75,
+  // conv_post / iSTFT / PQMF < 1), so whatever sits behind an utterance's limit — stale scratch — stays more than
+  // 6 frames away from its valid samples: those are bitwise the default's.  Column-tile maps are built on the device
+  // from ylen32 (no extra host sync), one per (rate, tile width) geometry.
+  constexpr int kTrimMargin = 32;
+  const bool trim = m->trim && zlens != nullptr && !m->splitk && c.decoder != MBV_DEC_SINGLEBAND;
+  struct TrimKey { int num, add, T, bn; const int* map; };
+  std::vector<TrimKey> trim_maps;
+  auto with_trim = [&](ConvArgs& a, int num, int add) {
+    if (!trim) return;
+    const int bn = conv1d_trim_bn(a);
+    if (!bn) return;
+    for (const auto& k : trim_maps)
+      if (k.num == num && k.add == add && k.T == a.T && k.bn == bn) { a.trim_map = k.map; a.trim_bn = bn; return; }
+    int* map = sc.take<int>(launch_trim_map_ints(B, a.T, bn));
+    launch_trim_map(zlens, B, num, num * kTrimMargin + add, a.T, bn, map, s_main);
+    trim_maps.push_back({num, add, a.T, bn, map});
+    a.trim_map = map; a.trim_bn = bn;
+  };
   {
     ConvArgs a = conv_args(m, m->conv_pre, z, (int64_t)I * zstride, Td, x0, (int64_t)C0 * Td, Td, B);
     a.x_rstride = zstride;
     a.in_lens = zlens;
+    with_trim(a, 1, 0);
     launch_conv1d(a, s);
   }
   m->stages["dec_conv_pre"] = {x0, (int64_t)B * C0 * Td};
@@ -900,6 +923,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       a.in_slope = kLrelu;
       a.epi = EPI_CONVT;
       a.convt_u = us;
+      with_trim(a, L / Td, 0);                      // tiles run over INPUT frames (rate of the stage below)
       launch_conv1d(a, s);
     } else {
       ConvTArgs a{};
@@ -954,6 +978,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
             a.accum_in = j == 0 ? nullptr : xs;
             a.out_scale = j == 2 ? (1.f / 3.f) : 1.f;
           }
+          with_trim(a, Lo / Td, 0);
           launch_conv1d(a, s);
           state = r;
         }
@@ -966,6 +991,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
           a.in_slope = kLrelu;
           if (q == 0) a.chan_add = cadd;
           own_ws(a);
+          with_trim(a, Lo / Td, 0);
           launch_conv1d(a, s);
         }
         {
@@ -983,6 +1009,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
             if (conc && j > 0) HIPCHK(m, hipStreamWaitEvent(s, m->ev_rb[j - 1], 0));   // xs of the ResBlock before
           }
           own_ws(a);
+          with_trim(a, Lo / Td, 0);
           launch_conv1d(a, s);
           if (conc && q == 2) HIPCHK(m, hipEventRecord(m->ev_rb[j], s));
         }
@@ -1026,6 +1053,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
                              (int64_t)prow * Fr, Fr, nb);
       a.in_slope = 0.01f;                              // F.leaky_relu default slope (models.py:363)
       a.reflect1 = 1;                                  // ReflectionPad1d((1,0)) (models.py:364)
+      if (nb == B) with_trim(a, L / Td, 1);            // (a split run keeps every tile: the maps are per full batch)
       launch_conv1d(a, s);
     }
     if (b0 == 0) HIPCHK(m, hipEventRecord(m->evk[1], s));   // (a split run interleaves conv_post and iSTFT launches: evk_split below)
@@ -1045,6 +1073,7 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
       ia.phase = outs && outs->phase ? outs->phase + (size_t)b0 * 36 * Fr : nullptr;
       ia.B = nb; ia.Tp = Td; ia.multistream = ms;
       ia.fixed_bank = !ia.multistream; ia.exact_math = m->exact_math; ia.prescaled = 1;
+      if (trim && nb == B && !ia.o_mb && !ia.spec && !ia.phase) ia.trim_lens = zlens;
       launch_istft_pqmf(ia, s);
     }
   }
@@ -1164,6 +1193,7 @@ size_t decoder_scratch_bytes(const mbv_config& c, int B, int Td) {
     n += (bc < (size_t)B ? bc : (size_t)B) * utt + (size_t)B * 256 * Td;
   }
   n += 6 * (size_t)B * C0;                                     // cond vectors
+  n += 12 * ((size_t)B + 2 + (size_t)B * ((us * us * Td + 1 + 127) / 128 + 1));   // trimmed decode: column-tile maps (ints)
   return n * sizeof(float) + 64 * 256 + 32 * 256;              // + the 256-byte alignment of every take
 }
 
@@ -1259,13 +1289,14 @@ int mbv_set_option(mbv_model* m, const char* name, int value) {
   if (!strcmp(name, "wn_fused")) { m->wn_fused = value != 0; return 0; }
   if (!strcmp(name, "xpost_chunk_bytes")) { m->xpost_chunk_bytes = value > 0 ? value : 0; return 0; }
   if (!strcmp(name, "dec_streams")) { m->dec_streams = value != 0; return 0; }
+  if (!strcmp(name, "trim")) { m->trim = value != 0; return 0; }
   if (!strcmp(name, "conv_bf16")) {
     if (value != 0 && value != 3) return m->fail("mbv_set_option: conv_bf16 takes 0 (exact fp32) or 3 (split-bf16, three products)");
     m->conv_bf16 = value;
     if (value == 3 && m->finalized && ensure_split_arena(m, nullptr)) return 1;
     return 0;
   }
-  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams, conv_bf16)", name);
+  return m->fail("mbv_set_option: unknown option '%s' (known: splitk, istft_exact, wn_fused, xpost_chunk_bytes, dec_streams, trim, conv_bf16)", name);
 }
 
 void mbv_destroy(mbv_model* m) {

@@ -281,8 +281,13 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 #define MBV_SETUP_TILE(TILE)                                                                 \
   {                                                                                          \
     const int tile_ = (TILE);                                                                \
-    const int tx_ = tile_ % tiles_x, rest_ = tile_ / tiles_x;                                \
-    lb = rest_ / tiles_y; lm0 = (rest_ % tiles_y) * BM; lt0 = tx_ * BN;                      \
+    if (a.trim_map) {                 /* compact list: (column tile of the map, row tile) */    \
+      const int ux_ = tile_ / tiles_y;                                                       \
+      lb = a.trim_map[a.B + 1 + ux_]; lm0 = (tile_ % tiles_y) * BM; lt0 = (ux_ - a.trim_map[lb]) * BN; \
+    } else {                                                                                 \
+      const int tx_ = tile_ % tiles_x, rest_ = tile_ / tiles_x;                              \
+      lb = rest_ / tiles_y; lm0 = (rest_ % tiles_y) * BM; lt0 = tx_ * BN;                    \
+    }                                                                                        \
     wlane = (PREC == 3 ? a.w_split : a.w) + (int64_t)wtap0 * tap_stride + ((int64_t)wrem0 * a.Mpad + lm0 + wq) * 4; \
     xb = a.x + (int64_t)lb * a.x_bstride;                                                    \
     const int len_in_ = a.in_lens ? a.in_lens[lb] : 0x7fffffff;                              \
@@ -403,6 +408,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   // workspace; the last one to arrive (ticket counter) sums them in split order on top of the
   // start values and runs the epilogue.  S == 1: a unit is a tile.
   const int S = NWN == 2 ? ksplit : 1;             // the 512-thread shape is only picked for launches that fill the chip
+  if (a.trim_map) total_tiles = a.trim_map[a.B] * tiles_y;    // trimmed decode: the tile count lives on the device
   const int total_units = total_tiles * S;
   __shared__ int s_ticket;
   int s_unit = blockIdx.x;
@@ -441,8 +447,14 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int tile = unit / S, sp = unit % S;
     const int c_lo = sp * nck / S, c_hi = (sp + 1) * nck / S;
-    const int tx = tile % tiles_x, rest = tile / tiles_x;
-    const int b = rest / tiles_y, m0 = (rest % tiles_y) * BM, t0 = tx * BN;
+    int b, m0, t0;
+    if (a.trim_map) {
+      const int ux = tile / tiles_y;
+      b = a.trim_map[a.B + 1 + ux]; m0 = (tile % tiles_y) * BM; t0 = (ux - a.trim_map[b]) * BN;
+    } else {
+      const int tx = tile % tiles_x, rest = tile / tiles_x;
+      b = rest / tiles_y; m0 = (rest % tiles_y) * BM; t0 = tx * BN;
+    }
     const int wrow0 = m0 + wm * 32 * WM;
     int nact = (a.M - wrow0 + 31) / 32;              // 32-row tiles of this wave that hold real rows
     nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
@@ -872,8 +884,12 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   static const int tiny_div = [] { const char* e = getenv("MBV_SPLITK_TINY"); return e ? atoi(e) : 16; }();
   const bool tiny = total * (long)tiny_div <= slots;
   const int min_chunks = tiny ? 2 : 4;
+  if (a.trim_map && a.trim_bn != BN) {
+    fprintf(stderr, "mbv: trimmed decode: tile map built for %d-column tiles, the launch uses %d\n", a.trim_bn, BN);
+    abort();
+  }
   if (NWN == 2 && splitk && a.ws && a.counters && total * 4 <= slots && nck >= (tiny ? 4 : 16) &&
-      total <= a.n_counters) {
+      total <= a.n_counters && !a.trim_map) {
     S = (int)(slots / total);
     if (S > nck / min_chunks) S = nck / min_chunks;
     if (S > 16) S = 16;
@@ -963,6 +979,25 @@ static void launch_ck(const ConvArgs& a, hipStream_t s) {
   else launch_one<WM, WN, 8, NWN>(a, s);
 }
 
+// trimmed decode: the column-tile width launch_conv1d will pick for this conv (the tile map is built for it)
+int conv1d_trim_bn(const ConvArgs& a) {
+  if (a.epi == EPI_LN || a.splitk) return 0;
+  {   // a conv that launch_conv1d sends to the narrow kernel (<= 256 frames) keeps that route: trimming must never
+      // change which kernel — i.e. which summation order — computes a sample
+    static const int narrow = [] { const char* e = getenv("MBV_CONV_NARROW"); return e ? atoi(e) : 1; }();
+    if (narrow && conv1d_narrow_supported(a) && (a.T <= 256 || narrow == 2)) return 0;
+  }
+  const bool wide_m = a.M > 64 || a.epi == EPI_GATE || a.epi == EPI_CONVT;
+  static const int mode = [] { const char* e = getenv("MBV_CONV_WIDE"); return e ? atoi(e) : 3; }();
+  if (wide_m && mode >= 3 && a.T >= 384) {
+    const double eff2 = 0.90 * a.T / (double)(((a.T + 127) / 128) * 128);
+    const double eff3 = a.T / (double)(((a.T + 383) / 384) * 384);
+    const long blocks3 = (long)((a.T + 383) / 384) * ((a.M + 127) / 128) * a.B;
+    if (eff3 >= eff2 && blocks3 >= 512) return 384;
+  }
+  return 128;
+}
+
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
   // conv1d_narrow.hip (32-column units, rows split over waves, weights from L2) takes over where the
   // 128-column tiles below fit badly:
@@ -979,7 +1014,7 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
       launch_conv1d_narrow(a, false, s);
       return;
     }
-    if (narrow && conv1d_narrow_supported(a)) {
+    if (narrow && !a.trim_map && conv1d_narrow_supported(a)) {
       const long tiles128 = (long)((a.T + 127) / 128) * ((a.M + 127) / 128) * a.B;
       // (fewer than 16 units — conv_o / conv_2 of the text encoder of one short utterance: 8 — are better
       // served by split-K over the long Cin loop than by 8 workgroups walking it alone; measured on ljs_mb,
@@ -1014,7 +1049,7 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
     // first utterances, the rest as 128 x 128 tiles on the 512 half-CU slots.  In units of one big tile's time
     // (a small tile on half a CU: 1/3 of the work on 1/2 of the waves, measured 0.63 - 0.65):
     static const int split_on = [] { const char* e = getenv("MBV_CONV_BATCH_SPLIT"); return e ? atoi(e) : 1; }();
-    if (split_on && !a.splitk && eff3 >= eff2 && blocks3 > 256 && a.B > 1) {
+    if (split_on && !a.splitk && !a.trim_map && eff3 >= eff2 && blocks3 > 256 && a.B > 1) {
       const double c2 = 0.65;
       auto rounds = [](long n, long slots) { return (double)((n + slots - 1) / slots); };
       double best = big ? rounds(blocks3, 256) : rounds(tpb2 * a.B, 512) * c2;

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
   }
   const int b = tile / tiles_per_utt;
   const int m0 = (tile % tiles_per_utt) * TM;
+  // opt-in trimmed decode: sub-band samples at and beyond 64 * trim_lens[b] belong to no valid frame; a tile
+  // wholly beyond is not computed (the caller zero-filled o), the tile across the boundary stores zeros there
+  const int m_valid = a.trim_lens ? 64 * a.trim_lens[b] : 0x7fffffff;
+  if (m0 >= m_valid) return;
   const int Tp = a.Tp;
   const int F = 16 * Tp + 1;
   const int M = 64 * Tp;                  // sub-band samples per band
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS, (2048 / NTHREADS) * (NTHREADS / 256)) voi
         }
       }
       *reinterpret_cast<float4*>(a.o + (int64_t)b * 4 * M + 4 * (int64_t)m) =
-          make_float4(acc[0], acc[1], acc[2], acc[3]);
+          m < m_valid ? make_float4(acc[0], acc[1], acc[2], acc[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }

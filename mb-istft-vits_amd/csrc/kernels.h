@@ -66,6 +66,12 @@ struct ConvArgs {
   float couple_sign;       // COUPLE: -1 reverse (x1 - m), +1 forward (x1 + m)
   int B;
   int debug;               // timing experiments only (MBV_CONV_DEBUG): 1 = no restaging, 3 = no MFMA
+  // r03, opt-in trimmed decode (mbv_set_option "trim"): only the column tiles that hold frames below a per-utterance
+  // limit exist as work.  trim_map (device, launch_trim_map): [0 .. B] prefix sums of ceil(limit_b / BN), then the
+  // utterance of every column tile; trim_bn = the BN it was built for (checked by the launcher).  The kernel walks
+  // (column tile, row tile) pairs of that compact list; nothing else changes.  nullptr: every tile (default).
+  const int* trim_map;
+  int trim_bn;
   // split-K scratch (small launches): partial accumulators + one self-resetting ticket per tile
   float* ws;
   size_t ws_floats;
@@ -200,6 +206,8 @@ struct IstftArgs {
   int prescaled;         // 1: x_post rows already carry log2(e) (magnitude) / 1/(2 pi) (phase)
   int polar_in;          // 1: x_post unused; spec / phase [B,4,9,F] are the INPUT (istft_finalize)
   int nt_stores;         // set by the launcher (MBV_ISTFT_NT, default 1): non-temporal stores for spec / phase / o_mb
+  const int* trim_lens;  // opt-in trimmed decode: [B] valid z-frames; samples at and beyond 256 * trim_lens[b] are not computed
+                         // (the caller zero-fills o; o_mb / spec / phase must be null)
 };
 void launch_istft_pqmf(const IstftArgs& a, hipStream_t s);
 
@@ -230,5 +238,11 @@ void launch_lens_to_i32(const int64_t* lens, int* out, int B, int T, int* bad, h
 
 // misc
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
+// trimmed decode: column-tile map of one conv geometry; limit_b = min(T, lens[b] * num + add) output frames.
+// out: (B + 1) + B * ceil(T / BN) ints (launch_trim_map_ints)
+size_t launch_trim_map_ints(int B, int T, int BN);
+void launch_trim_map(const int* lens, int B, int num, int add, int T, int BN, int* out, hipStream_t s);
+// which column-tile width launch_conv1d will use for this conv (128 or 384; 0: a kernel without trim support)
+int conv1d_trim_bn(const ConvArgs& a);
 
 }  // namespace mbv

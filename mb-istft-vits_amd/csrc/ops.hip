@@ -437,6 +437,39 @@ __global__ void fill_kernel(float* p, float v, int64_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// trimmed decode (ConvArgs::trim_map): per-utterance column-tile counts, their prefix sums and the tile -> utterance map
+__global__ void trim_map_kernel(const int* __restrict__ lens, int B, int num, int add, int T, int BN, int* __restrict__ out) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x;
+  const int per = (B + 255) / 256;
+  auto tiles_of = [&](int b) {
+    long lim = (long)lens[b] * num + add;
+    lim = lim < 0 ? 0 : (lim > T ? T : lim);
+    return (int)((lim + BN - 1) / BN);
+  };
+  int s = 0;
+  for (int i = 0; i < per; ++i) { const int b = tid * per + i; if (b < B) s += tiles_of(b); }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = 0; i < per; ++i) {
+    const int b = tid * per + i;
+    if (b < B) {
+      out[b] = run;
+      const int n = tiles_of(b);
+      for (int k = 0; k < n; ++k) out[B + 1 + run + k] = b;
+      run += n;
+      if (b == B - 1) out[B] = run;
+    }
+  }
+}
+size_t launch_trim_map_ints(int B, int T, int BN) { return (size_t)B + 1 + (size_t)B * ((T + BN - 1) / BN); }
+void launch_trim_map(const int* lens, int B, int num, int add, int T, int BN, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(trim_map_kernel, dim3(1), dim3(256), 0, s, lens, B, num, add, T, BN, out);
+}
+
 void launch_fill(float* p, float v, int64_t n, hipStream_t s) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -308,7 +308,7 @@ class SynthesizerTrn(nn.Module):
     @torch.no_grad()
     def _run(self, x, x_lengths, sid, noise_scale, length_scale, max_len, decode,
              frames_hook=None, noise_scale_w=1., noise_w=None, outputs=None, stat_reduce=None,
-             prior_rows=None):
+             prior_rows=None, trim=False):
         """One encode + synthesize pair.
           outputs      None = every tensor of the reference's 8-tuple; or a collection of names from
                        _OUTPUT_NAMES: only those are materialised (the others come back as None and
@@ -318,7 +318,8 @@ class SynthesizerTrn(nn.Module):
                        every rank pads to the global T'max and every rank raises when any does
           frames_hook  host-side override of T' (tests: pad a sub-batch like its parent batch)
           prior_rows   (lo, hi, B_global): draw the prior noise for the whole global batch and use
-                       rows lo:hi (ranks seeded alike then reproduce the single-process draw)"""
+                       rows lo:hi (ranks seeded alike then reproduce the single-process draw)
+          trim         opt-in trimmed decode (see `infer`)"""
         h = self._ensure_handle()
         L = _capi.lib()
         x, x_lengths, sid = self._check_inputs(x, x_lengths, sid)
@@ -380,18 +381,31 @@ class SynthesizerTrn(nn.Module):
                 if k in want:
                     t[k] = torch.empty(B, I, Tp, **f32)
             Td = Tp if max_len is None else max(0, min(Tp, int(max_len)))
+            if trim:
+                if want & {"o_mb", "spec", "phase"}:
+                    raise ValueError("trim=True materialises the waveform only: pass outputs=('o',) (+ attn / y_mask / z ...)")
+                if self.cfg.decoder == DEC_SB:
+                    raise ValueError("trim=True is built for the multiband / multistream decoders")
             if decode and want & {"o", "o_mb", "spec", "phase"}:
                 if Td <= 0:
                     raise ValueError("max_len leaves no frames to decode")
                 o, o_mb, spec, phase = self._alloc_decoder_outputs(B, Td, dev, want)
+                if trim and o is not None:
+                    o.zero_()                         # tiles behind an utterance's end are never written
                 t.update(o=o, o_mb=o_mb, spec=spec, phase=phase)
             for k, v in t.items():
                 if v is not None:
                     setattr(out, k, v.data_ptr())
             self._ticket += 1
-            _capi.check(h, L.mbv_synthesize(h, Tp, self._ptr(noise), float(noise_scale),
-                                            int(Td if max_len is not None else 0), C.byref(out), stream),
-                        "mbv_synthesize")
+            if trim:
+                _capi.check(h, L.mbv_set_option(h, b"trim", 1), "mbv_set_option")
+            try:
+                _capi.check(h, L.mbv_synthesize(h, Tp, self._ptr(noise), float(noise_scale),
+                                                int(Td if max_len is not None else 0), C.byref(out), stream),
+                            "mbv_synthesize")
+            finally:
+                if trim:
+                    _capi.check(h, L.mbv_set_option(h, b"trim", 0), "mbv_set_option")
         timings = Timings(self, self._ticket)
         g = t.get
         return (g("o"), g("o_mb"), g("spec"), g("phase"), g("attn"), g("y_mask"),
@@ -418,15 +432,20 @@ class SynthesizerTrn(nn.Module):
         return o, o_mb, spec, phase
 
     def infer(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
-              max_len=None, outputs=None):
+              max_len=None, outputs=None, trim=False):
         """-> (o, o_mb, spec, phase, attn, y_mask, (z, z_p, m_p, logs_p), timings)  (models.py:737)
 
         `outputs` (extension, default None = the reference's full tuple): names of the tensors to
         materialise; the rest of the tuple is None.  A caller that only takes `[0]`
         (tts_vits.py:134-137, synthesis_module.py:178-189) passes `outputs=("o",)` and gets the
-        waveform-only launch of the fused iSTFT+PQMF stage (no spec / phase / o_mb / attn stores)."""
+        waveform-only launch of the fused iSTFT+PQMF stage (no spec / phase / o_mb / attn stores).
+
+        `trim` (extension, default False; needs `outputs` without o_mb / spec / phase): opt-in trimmed decode for
+        ragged batches — per utterance the decoder only computes what its valid 256 * y_lengths[b] samples depend
+        on (frames below y_lengths[b] + 32).  Those samples are bitwise the default's; the padded region of `o`,
+        which the reference's unmasked decoder fills with defined values, comes back as zeros."""
         r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
-                      noise_scale_w=noise_scale_w, outputs=outputs)
+                      noise_scale_w=noise_scale_w, outputs=outputs, trim=trim)
         return r[:8]
 
     def infer_z_only(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1, noise_scale_w=1.,
@@ -437,11 +456,11 @@ class SynthesizerTrn(nn.Module):
         return r[4], r[5], r[6], r[7]
 
     def infer_with_lengths(self, x, x_lengths, sid=None, noise_scale=1, length_scale=1,
-                           max_len=None, noise_scale_w=1., outputs=None):
+                           max_len=None, noise_scale_w=1., outputs=None, trim=False):
         """`infer` plus the per-utterance frame counts y_lengths [B] (int64) — what a batched
         caller needs to trim the padded waveforms (valid samples = 256 * y_lengths)."""
         r = self._run(x, x_lengths, sid, noise_scale, length_scale, max_len, decode=True,
-                      noise_scale_w=noise_scale_w, outputs=outputs)
+                      noise_scale_w=noise_scale_w, outputs=outputs, trim=trim)
         return r[:8], r[8]
 
     @torch.no_grad()

@@ -77,6 +77,27 @@ int main(int argc, char** argv) {
       }
     }
     if (!nwg) continue;
+    {   // per tile of a workgroup (in the order it walks them): tile start -> epilogue issued, and the MFMA loops inside
+      double tt[32] = {0}, tl[32] = {0}, t_first = 0; long tn[32] = {0};
+      for (int wg = 0; wg < NWG; ++wg) {
+        const unsigned long long* s = &st[((size_t)wg * 2 + smp) * 512];
+        const int n = (int)s[0];
+        if (n < 2) continue;
+        int tile = -1; unsigned long long t1 = 0, t3 = 0;
+        t_first += ((s[1] >> 4) - first) * 0.01;
+        for (int i = 1; i <= n; ++i) {
+          const int id = s[i] & 15; const unsigned long long t = s[i] >> 4;
+          if (id == 1) { ++tile; t1 = t; }
+          if (tile < 0 || tile >= 32) continue;
+          if (id == 3) t3 = t;
+          if (id == 4) tl[tile] += (t - t3) * 0.01;
+          if (id == 8) { tt[tile] += (t - t1) * 0.01; ++tn[tile]; }
+        }
+      }
+      printf("-- sampled thread %d, per tile in walking order (us: whole tile | its MFMA loops):", smp * 256);
+      for (int k = 0; k < 32 && tn[k]; ++k) printf("  [%d] %.1f | %.1f", k, tt[k] / tn[k], tl[k] / tn[k]);
+      printf("\n   first stamp of a workgroup after the launch's first stamp: mean %.2f us\n", t_first / nwg);
+    }
     printf("-- sampled thread %d: %d workgroups, mean first->last stamp %.1f us, launch-wide first->last %.1f us\n", smp * 256, nwg, span / nwg, (last - first) * 0.01);
     double tot = 0;
     for (auto& kv : sum) tot += kv.second / nwg;

@@ -626,3 +626,39 @@ def test_set_option_splitk_in_process():
         assert not torch.equal(o1, o0)                   # the split path really ran (other summation order)
     with pytest.raises(_capi.MbvError):
         net.set_option("no-such-option", 1)
+
+
+@pytest.mark.timeout(900)
+def test_trimmed_decode_is_bitwise_the_default_on_valid_samples():
+    """Opt-in `infer(..., outputs=("o",), trim=True)`: per utterance the decoder computes only what its valid
+    256 * y_lengths[b] samples depend on.  Those samples must be BITWISE the default call's, the padded region
+    zero — also when the scratch behind an utterance's limit holds the leftovers of a longer batch (run first),
+    with speaker conditioning, with max_len, and at the full bench size."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    for cfg_name, B, T, ml in (("ljs_mb_istft_vits", 9, 110, None), ("uudb_ms_istft_vits_ms", 6, 90, None),
+                               ("ljs_ms_istft_vits", 5, 140, 300), ("ljs_mb_istft_vits", 64, 200, None)):
+        net, _ = make_net(cfg_name)
+        # leftovers: one batch of long utterances through the same scratch arena first
+        xl_, xll_, sid_ = synth.synthetic_batch(net.cfg, B, T, seed=5)
+        net.infer(torch.from_numpy(xl_).cuda(), torch.from_numpy(xll_).cuda(),
+                  torch.from_numpy(sid_).cuda() if sid_ is not None else None, noise_scale=0, length_scale=1, outputs=("o",))
+        x, xl, sid = synth.synthetic_batch(net.cfg, B, T, seed=6, ragged=True)
+        xl[0] = max(3, T // 5)                            # one very short utterance
+        xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+        sg = torch.from_numpy(sid).cuda() if sid is not None else None
+        (o_ref, *_), ylen = net.infer_with_lengths(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=("o",), max_len=ml)
+        (o_trim, *rest), ylen2 = net.infer_with_lengths(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=("o", "z"),
+                                                       max_len=ml, trim=True)
+        assert torch.equal(ylen, ylen2) and o_trim.shape == o_ref.shape and rest[5][0] is not None
+        spf = net.cfg.samples_per_frame
+        for b in range(B):
+            n = min(int(ylen[b]) * spf, o_ref.shape[-1])
+            assert torch.equal(o_trim[b, 0, :n], o_ref[b, 0, :n]), (cfg_name, b)
+            assert not bool(o_trim[b, 0, n:].any()), (cfg_name, b)
+        assert int(ylen.min()) < int(ylen.max())          # the batch really is ragged
+        # the default is untouched by the option having been used
+        o_again = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=("o",), max_len=ml)[0]
+        assert torch.equal(o_again, o_ref)
+    with pytest.raises(ValueError):
+        net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, trim=True)          # all outputs + trim
