@@ -191,6 +191,11 @@ int mbv_set_option(mbv_model *m, const char *name, int value);
  * [text_encoder, duration_predictor, alignment_and_projection, flow,
  * waveform_decoder].  Synchronises on the recorded events. */
 int mbv_stage_times_ms(mbv_model *m, float out[5]);
+/* The same for an earlier call of this handle: mbv_ticket() after mbv_encode names the call (1, 2, ...); the stage
+ * events of the last 8 calls are kept, so a caller that reads its timings late (the reference's `timings` dict is
+ * often never read) still gets them after newer calls have started.  Fails for a call older than that. */
+int64_t mbv_ticket(mbv_model *m);
+int mbv_stage_times_ms_at(mbv_model *m, int64_t ticket, float out[5]);
 
 /* Kernel-level timers of the last mbv_synthesize / mbv_decode (HIP events on the
  * launch stream, used by bench.py for the roofline lines):

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mbv_finalize_weights", "mbv_missing_weights", "mbv_encode", "mbv_synthesize", "mbv_decode",
     "mbv_speaker_embedding", "mbv_stage_times_ms", "mbv_istft_pqmf", "mbv_read_stage",
     "mbv_op_conv1d", "mbv_kernel_times_ms", "mbv_istft_finalize", "mbv_pcm16", "mbv_voice_conversion",
-    "mbv_set_option", "mbv_arena_floats", "mbv_export_arena", "mbv_import_arena",
+    "mbv_set_option", "mbv_arena_floats", "mbv_export_arena", "mbv_import_arena", "mbv_ticket", "mbv_stage_times_ms_at",
 ]
 
 
@@ -92,6 +92,9 @@ def lib():
     L.mbv_voice_conversion.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MbvOutputs), vp, vp]
     L.mbv_pcm16.argtypes = [vp, vp, vp, i32, C.c_int64, i32, vp, vp]
     L.mbv_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.mbv_ticket.argtypes = [vp]
+    L.mbv_ticket.restype = C.c_int64
+    L.mbv_stage_times_ms_at.argtypes = [vp, C.c_int64, C.POINTER(C.c_float * 5)]
     L.mbv_arena_floats.argtypes = [vp]
     L.mbv_arena_floats.restype = C.c_int64
     L.mbv_export_arena.argtypes = [vp, vp, C.c_int64, vp]

@@ -74,7 +74,8 @@ struct mbv_model {
   struct Dds { PVec sw[3], sb[3], g1[3], b1[3], g2[3], b2[3]; PConv c1[3]; };
   struct SdpFlow { PVec pre_w, pre_b; Dds dds; PConv proj; };
   struct Sdp { PConv pre, proj; Dds dds; SdpFlow flow[3]; PVec m, logs; float edge_const = 0.f; } sdp;
-  struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers], in16[kFlowLayers], rsp[kFlowLayers]; PVec cw, cb; };
+  struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers], in16[kFlowLayers], rsp[kFlowLayers]; PVec cw, cb;
+                PConv rspf[kFlowLayers]; };   // rspf: res/skip convs with `post` folded into their skip rows (wn_fused.hip, r03)
   Flow flow[kNFlows];
   PConv conv_pre, conv_post;
   static constexpr int kEncQLayers = 16;     // models.py:646
@@ -108,7 +109,11 @@ struct mbv_model {
   int *lens32 = nullptr, *cum = nullptr, *ylen32 = nullptr;
   std::map<std::string, StageRef> stages;
 
-  hipEvent_t ev[7]{};
+  static constexpr int kEvRing = 8;
+  hipEvent_t evr[kEvRing][7]{};    // stage events of the last kEvRing encode (+ synthesize) calls
+  hipEvent_t* ev = evr[0];         // ... of the current call
+  int64_t ticket = 0;              // calls of mbv_encode so far; slot = ticket % kEvRing
+  bool evr_a[kEvRing]{}, evr_b[kEvRing]{};
   hipEvent_t evk[3]{};          // decoder start / before istft / after istft
   // the three ResBlocks of a decoder stage on three streams when one of them cannot fill the chip (run_decoder)
   hipStream_t aux[2]{};
@@ -658,6 +663,45 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       std::vector<int> rows(half);
       for (int r = 0; r < half; ++r) rows[r] = flipped ? half - 1 - r : r;
       F.post = P.conv(w, half, H, 1, rows, {}, &P.t(s + "post.bias").data, nullptr);
+      // r03: `post` folded into the res/skip convs of the fused WN layers.  m = post(sum_l skip_l) is linear in the
+      // layers' gated tiles: m = sum_l (W_post W_rs_l[skip rows]) acts_l + (W_post sum_l b_rs_l[skip] + b_post), so
+      // layer l's res/skip conv gets `half` skip rows (W_post W_rs_l[skip rows], composed in fp64) instead of H,
+      // `skip` accumulates m itself and the last layer applies the coupling (WnLayerArgs::x1).  Row r of m is the
+      // physical channel r of the half being updated (the Flip folded as in F.post above).
+      if (wn_fused_supported(H, kFlowK)) {
+        const std::vector<float>& bpost = P.t(s + "post.bias").data;
+        for (int l = 0; l < kFlowLayers; ++l) {
+          const std::string q = s + "enc.res_skip_layers." + std::to_string(l);
+          const std::vector<float> wrs = P.dense(q);                 // [2H or H][H][1]
+          const std::vector<float>& brs = P.t(q + ".bias").data;
+          const bool lastl = l == kFlowLayers - 1;
+          const int skip0 = lastl ? 0 : H;                            // first skip row of W_rs_l
+          const int Mrows = (lastl ? 0 : H) + half;
+          std::vector<float> wc((size_t)Mrows * H), bc(Mrows);
+          for (int r = 0; r < (lastl ? 0 : H); ++r) {
+            std::memcpy(&wc[(size_t)r * H], &wrs[(size_t)r * H], (size_t)H * sizeof(float));
+            bc[r] = brs[r];
+          }
+          for (int r = 0; r < half; ++r) {
+            const int pr = rows[r];
+            std::vector<double> acc(H, 0.0);
+            double bacc = lastl ? (double)bpost[pr] : 0.0;
+            for (int k = 0; k < H; ++k) {
+              const double wp = w[(size_t)pr * H + k];
+              const float* src = &wrs[(size_t)(skip0 + k) * H];
+              for (int cch = 0; cch < H; ++cch) acc[cch] += wp * src[cch];
+              bacc += wp * brs[skip0 + k];
+            }
+            float* dst = &wc[(size_t)((lastl ? 0 : H) + r) * H];
+            for (int cch = 0; cch < H; ++cch) dst[cch] = (float)acc[cch];
+            bc[(lastl ? 0 : H) + r] = (float)bacc;
+          }
+          std::vector<int> rws(Mrows), cmap(H);
+          for (int i = 0; i < Mrows; ++i) rws[i] = i;
+          for (int ci = 0; ci < H; ++ci) cmap[ci] = 8 * (ci / 8) + 4 * (ci & 1) + ((ci & 7) >> 1);     // as pack_rs_permuted
+          F.rspf[l] = P.conv(wc, Mrows, H, 1, rws, cmap, &bc, nullptr);
+        }
+      }
     }
   }
 
@@ -1093,9 +1137,19 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
 // and only where the frame mask is 1 (every reader masks on load).
 // Two-launch path (MBV_WN_FUSED=0; experiments: MBV_WN_SMALL=<tiles> in the low-latency mode): gate conv,
 // then res/skip conv.
+struct WnFold { const PConv* rspf; int Cs; float* x1; int64_t x1_bstride; float sign; };
+// can this WN stack take the fused one-launch-per-layer kernel (run_wn's own test; run_coupling asks before it folds `post`)
+bool wn_takes_fused(const mbv_model* m, const PConv* in_l, const PConv* in16_l, int B, int T) {
+  const int H = m->cfg.hidden_channels;
+  static const int small_units = [] { const char* e = getenv("MBV_WN_SMALL"); return e ? atoi(e) : 0; }();
+  const bool small = (long)B * ((T + 31) / 32) < small_units;
+  static const int wn_bf16 = [] { const char* e = getenv("MBV_WN_BF16"); return e ? atoi(e) : 1; }();
+  const bool two_launch_bf16 = wn_bf16 && m->Wsplit(0) != nullptr && (long)B * T >= 12288;
+  return !two_launch_bf16 && m->wn_fused && in16_l[0].M && wn_fused_supported(H, in_l[0].K) && wn_fused_fits(B, H, T) && !(m->splitk && small);
+}
 int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16_l, const PConv* rsp_l, int nl,
            const PVec& cw, const PVec& cb, const float* gvec, float* hbuf, float* acts, float* skip, float* gc,
-           int* ustart, const int* lens, int B, int T, hipStream_t s) {
+           int* ustart, const int* lens, int B, int T, hipStream_t s, const WnFold* fold = nullptr) {
   const mbv_config& c = m->cfg;
   const int H = c.hidden_channels, gin = c.gin_channels;
   const int64_t bsH = (int64_t)H * T;
@@ -1121,10 +1175,15 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
       a.h_in = hin; a.h_out = hout; a.skip = skip; a.lens = lens; a.ustart = ustart; a.hmap = hmap;
       a.wg = m->W(in16_l[l].w); a.bg = m->W(in16_l[l].bias);
       if (cond) { a.gcond = gc + (size_t)l * 2 * H; a.gcond_bstride = 2 * H * nl; }
-      a.wr = m->W(rsp_l[l].w); a.br = m->W(rsp_l[l].bias);
+      const PConv& R = fold ? fold->rspf[l] : rsp_l[l];
+      a.wr = m->W(R.w); a.br = m->W(R.bias);
       a.B = B; a.H = H; a.T = T;
-      a.Mg_pad = in16_l[l].Mpad; a.Mr = rsp_l[l].M; a.Mr_pad = rsp_l[l].Mpad;
-      a.last = rsp_l[l].M == H; a.skip_accum = l > 0;
+      a.Mg_pad = in16_l[l].Mpad; a.Mr = R.M; a.Mr_pad = R.Mpad;
+      a.last = l == nl - 1; a.skip_accum = l > 0;
+      if (fold) {
+        a.Cs = fold->Cs;
+        if (a.last) { a.x1 = fold->x1; a.x1_bstride = fold->x1_bstride; a.couple_sign = fold->sign; }
+      }
       launch_wn_layer(a, s);
       float* tmp = hin; hin = hout; hout = tmp;
     }
@@ -1164,6 +1223,13 @@ int run_coupling(mbv_model* m, int f, bool reverse, float* z, const float* gvec,
     ConvArgs a = conv_args(m, F.pre, x0, bsI, T, hbuf, bsH, T, B);
     a.out_lens = lens;
     launch_conv1d(a, s);
+  }
+  static const int fold_env = [] { const char* e = getenv("MBV_FLOW_FOLD"); return e ? atoi(e) : 1; }();
+  if (fold_env && F.rspf[0].M && wn_takes_fused(m, F.in, F.in16, B, T)) {
+    // `post` lives in the res/skip convs (do_finalize): the last WN layer applies the coupling on the valid frames.
+    // Frames at and beyond lens[b] are not touched: z arrives masked (expand_kernel / posterior_sample) and stays so.
+    const WnFold fold{F.rspf, half, x1, bsI, reverse ? -1.f : 1.f};
+    return run_wn(m, F.in, F.rs, F.in16, F.rsp, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, ustart, lens, B, T, s, &fold);
   }
   run_wn(m, F.in, F.rs, F.in16, F.rsp, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, ustart, lens, B, T, s);
   {
@@ -1249,8 +1315,9 @@ int mbv_create(const mbv_config* cfg, mbv_model** out) {
   { const char* e = getenv("MBV_CONV_SPLITK"); m->splitk = (e && atoi(e) != 0) ? 1 : 0; }
   { const char* e = getenv("MBV_WN_FUSED"); m->wn_fused = e ? (atoi(e) != 0) : 1; }
   build_expected(m);
-  for (auto& e : m->ev)
-    if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
+  for (auto& set : m->evr)
+    for (auto& e : set)
+      if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   for (auto& e : m->evk)
     if (hipEventCreate(&e) != hipSuccess) { delete m; return bad("hipEventCreate failed"); }
   m->ev_ok = true;
@@ -1310,7 +1377,7 @@ void mbv_destroy(mbv_model* m) {
   if (m->scrB) (void)hipFree(m->scrB);
   if (m->user_tab) (void)hipFree(m->user_tab);
   if (m->peak_buf) (void)hipFree(m->peak_buf);
-  if (m->ev_ok) { for (auto& e : m->ev) (void)hipEventDestroy(e); for (auto& e : m->evk) (void)hipEventDestroy(e); }
+  if (m->ev_ok) { for (auto& set : m->evr) for (auto& e : set) if (e) (void)hipEventDestroy(e); for (auto& e : m->evk) (void)hipEventDestroy(e); }
   if (m->aux_ok) {
     for (auto& st : m->aux) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     (void)hipEventDestroy(m->ev_fork);
@@ -1458,6 +1525,10 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   float* dpc = sc.take<float>((size_t)B * H);
   m->stages.clear();
 
+  ++m->ticket;                                     // a new call: its own set of stage events (mbv_stage_times_ms_at)
+  m->ev = m->evr[m->ticket % mbv_model::kEvRing];
+  m->evr_a[m->ticket % mbv_model::kEvRing] = false;
+  m->evr_b[m->ticket % mbv_model::kEvRing] = false;
   HIPCHK(m, hipEventRecord(m->ev[0], s));
   launch_embed(ids, lengths, m->W(m->emb.off), x, m->lens32, bad, B, T, H, c.n_vocab, s);
   const int64_t bsH = (int64_t)H * T;
@@ -1590,6 +1661,7 @@ int mbv_encode(mbv_model* m, const int64_t* ids, const int64_t* lengths, const i
   HIPCHK(m, hipEventRecord(m->ev[2], s));
   HIPCHK(m, hipGetLastError());
   m->B = B; m->T = T; m->encoded = true; m->ev_a = true; m->ev_b = false;
+  m->evr_a[m->ticket % mbv_model::kEvRing] = true;
   m->stages["x_enc"] = {x, (int64_t)BT * H};
   m->stages["stats"] = {m->stats, (int64_t)BT * 2 * I};
   m->stages["logw"] = {m->logw, (int64_t)BT};
@@ -1642,6 +1714,7 @@ int mbv_synthesize(mbv_model* m, int t_frames, const float* noise, float noise_s
   HIPCHK(m, hipEventRecord(m->ev[6], s));
   HIPCHK(m, hipGetLastError());
   m->ev_b = true;
+  m->evr_b[m->ticket % mbv_model::kEvRing] = true;
   return 0;
 }
 
@@ -1672,6 +1745,26 @@ int mbv_stage_times_ms(mbv_model* m, float out[5]) {
   HIPCHK(m, hipEventElapsedTime(&out[2], m->ev[3], m->ev[4]));
   HIPCHK(m, hipEventElapsedTime(&out[3], m->ev[4], m->ev[5]));
   HIPCHK(m, hipEventElapsedTime(&out[4], m->ev[5], m->ev[6]));
+  return 0;
+}
+
+int64_t mbv_ticket(mbv_model* m) { return m ? m->ticket : -1; }
+
+int mbv_stage_times_ms_at(mbv_model* m, int64_t ticket, float out[5]) {
+  if (!m || !out) return 1;
+  DEVICE_GUARD(m);
+  if (ticket <= 0 || ticket > m->ticket) return m->fail("mbv_stage_times_ms_at: ticket %lld was never issued", (long long)ticket);
+  if (ticket <= m->ticket - mbv_model::kEvRing)
+    return m->fail("mbv_stage_times_ms_at: the events of call %lld were reused (%d calls are kept)", (long long)ticket, mbv_model::kEvRing);
+  const int slot = (int)(ticket % mbv_model::kEvRing);
+  if (!m->evr_a[slot] || !m->evr_b[slot]) return m->fail("call %lld has no completed encode+synthesize pair to time", (long long)ticket);
+  hipEvent_t* ev = m->evr[slot];
+  HIPCHK(m, hipEventSynchronize(ev[6]));
+  HIPCHK(m, hipEventElapsedTime(&out[0], ev[0], ev[1]));
+  HIPCHK(m, hipEventElapsedTime(&out[1], ev[1], ev[2]));
+  HIPCHK(m, hipEventElapsedTime(&out[2], ev[3], ev[4]));
+  HIPCHK(m, hipEventElapsedTime(&out[3], ev[4], ev[5]));
+  HIPCHK(m, hipEventElapsedTime(&out[4], ev[5], ev[6]));
   return 0;
 }
 

@@ -118,6 +118,13 @@ struct WnLayerArgs {
   int last;                // Mr == H: every row goes to skip
   int skip_accum;          // skip += (layers > 0) instead of skip =
   int debug;               // set by the launcher (MBV_WN_DEBUG_A): timing experiments, results wrong by design
+  // r03: the coupling layer's 1x1 `post` conv (modules.py:346-350) folded into the res/skip convs: their skip rows are
+  // W_post . W_rs[skip rows] (Cs = I/2 rows instead of H), so `skip` accumulates m = post(sum of skips) directly and
+  // the LAST layer applies the coupling x1 = (x1 + couple_sign * m) on its valid frames instead of storing skip.
+  int Cs;                  // channels of `skip` ([B, Cs, T]); 0: H (unfolded)
+  float* x1;               // last layer only: the half of z the coupling updates, [B, x1_bstride / T ..] rows Cs; nullptr: store skip
+  int64_t x1_bstride;      // elements between utterances of x1 (I * T)
+  float couple_sign;       // -1 reverse (x1 - m), +1 forward (x1 + m)
 };
 bool wn_fused_supported(int H, int K);
 bool wn_fused_fits(int B, int H, int T);      // h / skip small enough for the kernel's 32-bit offsets

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const float* m_t, const flo
     if (m_p) m_p[o] = m;
     if (logs_p) logs_p[o] = lg;
     if (z_p) z_p[o] = zp;
-    z[o] = zp;
+    z[o] = tp < yl ? zp : 0.f;       // z enters the flows masked (the reference masks it in the first coupling that updates a half;
+                                     // the fused WN layers only touch valid frames, wn_fused.hip); z_p keeps the reference's unmasked draw
   }
 }
 

@@ -119,8 +119,11 @@ __device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, unsig
 // MFMAs and nothing else: their weight / bias reads fall outside the buffer ranges or into padding
 // (garbage in, never used), and their loads / stores of h / skip are skipped by a wave-uniform test.
 struct WnCtx {
-  __amdgpu_buffer_rsrc_t wg_rs, wr_rs, bg_rs, br_rs, gc_rs, hin_rs, hout_rs, skip_rs;
+  __amdgpu_buffer_rsrc_t wg_rs, wr_rs, bg_rs, br_rs, gc_rs, hin_rs, hout_rs, skip_rs, x1_rs;
   unsigned wg_voff, wr_voff, wg_step, wr_step, rowT, io_voff, gc_voff;
+  unsigned sk_voff, x1_voff;     // lane offsets into skip ([B, Cs, T]) and into the coupled half of z (last layer, folded post)
+  float couple_sign;
+  int couple;                    // last layer applies x1 += sign * (skip + rs) instead of storing skip
   int xoff;                      // lane's column in the input-window image: half * kXS + (l31 & 15)
   int G, H, Mr, wave, hl, l31, last, skip_accum, exact_gate;
 };
@@ -241,7 +244,7 @@ __device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const f32x4* Xs,
             const int ch = row0 + 8 * q + 4 * c.hl + s;         // (ch & 7) = 4 hl + s
             v += xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
           } else if (c.skip_accum) {
-            v += bload1(c.skip_rs, c.io_voff, (srow0 + 8 * q + s) * c.rowT);
+            v += bload1(c.skip_rs, c.sk_voff, (srow0 + 8 * q + s) * c.rowT);
           }
         }
         acr[j][r] = v;
@@ -289,11 +292,22 @@ __device__ __forceinline__ void rs_store(const f32x16 (&acr)[NRT], const WnCtx& 
     if (row0 >= c.Mr) continue;
     const bool is_res = !c.last && row0 < c.H;
     const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
+    if (!is_res && c.couple) {
+      // folded post, last layer: acr = m (bias + the skips of the layers before + this layer's): the coupling itself.
+      // All 16 loads of x1 first, then the stores (one in-order counter for both on gfx9)
+      float xv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xv[r] = bload1(c.x1_rs, c.x1_voff, (srow0 + (unsigned)((r & 3) + 8 * (r >> 2))) * c.rowT);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        bstore1(xv[r] + c.couple_sign * acr[j][r], c.x1_rs, c.x1_voff, (srow0 + (unsigned)((r & 3) + 8 * (r >> 2))) * c.rowT);
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
       if (is_res) bstore1(acr[j][r], c.hout_rs, c.io_voff, (unsigned)(row0 + k) * c.rowT);
-      else bstore1(acr[j][r], c.skip_rs, c.io_voff, (srow0 + k) * c.rowT);
+      else bstore1(acr[j][r], c.skip_rs, c.sk_voff, (srow0 + k) * c.rowT);
     }
   }
 }
@@ -330,7 +344,11 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   const unsigned all_bytes = (unsigned)a.B * (unsigned)H * c.rowT;
   c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in), 0, all_bytes, kRsrcFlags);
   c.hout_rs = __builtin_amdgcn_make_buffer_rsrc(a.h_out, 0, a.last ? 0 : all_bytes, kRsrcFlags);
-  c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip, 0, all_bytes, kRsrcFlags);
+  const int Cs = a.Cs ? a.Cs : H;
+  c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip, 0, (unsigned)a.B * (unsigned)Cs * c.rowT, kRsrcFlags);
+  c.couple = a.last && a.x1 != nullptr;
+  c.couple_sign = a.couple_sign;
+  c.x1_rs = __builtin_amdgcn_make_buffer_rsrc(a.x1, 0, c.couple ? (unsigned)(a.B * a.x1_bstride * 4) : 0, kRsrcFlags);
   c.gc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcond), 0, a.gcond ? a.B * a.gcond_bstride * 4 : 0, kRsrcFlags);
   const int half = c.l31 >> 4, jl = c.l31 & 15;
   c.xoff = half * kXS + jl;
@@ -353,6 +371,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
       const int t = (half ? ht0[1] : ht0[0]) + jl;          // this lane's frame
       const bool tv = t < (half ? hlen[1] : hlen[0]);
       c.io_voff = tv ? (unsigned)((b * H + 4 * c.hl) * T + t) * 4u : kOob;
+      c.sk_voff = tv ? (unsigned)((b * Cs + 4 * c.hl) * T + t) * 4u : kOob;
+      c.x1_voff = tv ? (unsigned)(b * a.x1_bstride + (int64_t)(4 * c.hl) * T + t) * 4u : kOob;
       c.gc_voff = (unsigned)(b * a.gcond_bstride + 4 * c.hl) * 4u;
     }
 

@@ -49,8 +49,8 @@ class Timings(dict):
     HIP events so that `infer` itself never blocks: the first READ of any kind (indexing, get,
     items/keys/values, iteration, copy, ==, repr, json.dumps, pickle, dict(t)) waits for the call's
     last kernel and fills in the five stage times.  Until then the stored values are NaN
-    placeholders.  The events belong to the model handle: if a later `infer` on the same model has
-    started before this dict was first read, the values stay NaN (that call's timings replace them)."""
+    placeholders.  The handle keeps the events of its last 8 calls (`mbv_stage_times_ms_at`): a dict
+    read after more than 7 later calls on the same model stays NaN."""
 
     def __init__(self, owner, ticket):
         super().__init__((k, float("nan")) for k in _STAGES)
@@ -295,11 +295,12 @@ class SynthesizerTrn(nn.Module):
         return x, x_lengths, sid
 
     def _stage_times(self, ticket):
-        if ticket != self._ticket or self._handle is None:
-            return [float("nan")] * 5               # a later infer re-used the events
+        if self._handle is None or ticket[0] is not self._handle:
+            return [float("nan")] * 5               # the handle was re-created (device move)
         buf = (C.c_float * 5)()
-        _capi.check(self._handle, _capi.lib().mbv_stage_times_ms(self._handle, C.byref(buf)),
-                    "mbv_stage_times_ms")
+        with torch.cuda.device(self._device()):
+            if _capi.lib().mbv_stage_times_ms_at(self._handle, ticket[1], C.byref(buf)):
+                return [float("nan")] * 5           # more than 8 later calls: the events were reused
         return [v * 1e-3 for v in buf]              # reference reports seconds
 
     # ------------------------------------------------------------------ API
@@ -406,7 +407,7 @@ class SynthesizerTrn(nn.Module):
             finally:
                 if trim:
                     _capi.check(h, L.mbv_set_option(h, b"trim", 0), "mbv_set_option")
-        timings = Timings(self, self._ticket)
+        timings = Timings(self, (h, int(L.mbv_ticket(h))))
         g = t.get
         return (g("o"), g("o_mb"), g("spec"), g("phase"), g("attn"), g("y_mask"),
                 (g("z"), g("z_p"), g("m_p"), g("logs_p")), timings, y_lengths)

@@ -662,3 +662,19 @@ def test_trimmed_decode_is_bitwise_the_default_on_valid_samples():
         assert torch.equal(o_again, o_ref)
     with pytest.raises(ValueError):
         net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, trim=True)          # all outputs + trim
+
+
+def test_timings_of_earlier_calls_stay_readable():
+    """The reference's `timings` dict is usually read late or never; ours resolves lazily from HIP events.  The
+    handle keeps the events of its last 8 calls, so a dict read after newer calls still holds its own call's
+    stage times (r02: it turned into NaNs as soon as another infer had started)."""
+    from gpu_util import make_net
+    from mb_istft_vits_amd import synth
+    net, _ = make_net("ljs_mini_mb_istft_vits")
+    x, xl, _ = synth.synthetic_batch(net.cfg, 2, 20, seed=1)
+    xg, xlg = torch.from_numpy(x).cuda(), torch.from_numpy(xl).cuda()
+    ts = [net.infer(xg, xlg, noise_scale=0, length_scale=1)[7] for _ in range(10)]
+    late = dict(ts[-6])                                  # five calls later
+    assert all(np.isfinite(v) and v >= 0 for v in late.values()) and late["waveform_decoder"] > 0
+    assert all(np.isnan(v) for v in dict(ts[0]).values())      # ten calls later: reused, NaN by contract
+    assert all(np.isfinite(v) for v in dict(ts[-1]).values())
