@@ -75,7 +75,8 @@ struct mbv_model {
   struct SdpFlow { PVec pre_w, pre_b; Dds dds; PConv proj; };
   struct Sdp { PConv pre, proj; Dds dds; SdpFlow flow[3]; PVec m, logs; float edge_const = 0.f; } sdp;
   struct Flow { PConv pre, post, in[kFlowLayers], rs[kFlowLayers], in16[kFlowLayers], rsp[kFlowLayers]; PVec cw, cb;
-                PConv rspf[kFlowLayers]; };   // rspf: res/skip convs with `post` folded into their skip rows (wn_fused.hip, r03)
+                PConv rspf[kFlowLayers];      // rspf: res/skip convs with `post` folded into their skip rows (wn_fused.hip, r03)
+                PConv in16f0, pref; int Gi = 0; };   // `pre` folded too: layer 0's gate conv on [x0 ; mask] (composite weights), W_pre' for the residual rows
   Flow flow[kNFlows];
   PConv conv_pre, conv_post;
   static constexpr int kEncQLayers = 16;     // models.py:646
@@ -645,6 +646,50 @@ int do_finalize(mbv_model* m, hipStream_t stream) {
       for (int ci = 0; ci < half; ++ci) cmap[ci] = flipped ? half - 1 - ci : ci;
       F.pre = P.conv(w, H, half, 1, rows, cmap, &P.t(s + "pre.bias").data, nullptr);
     }
+    if (wn_fused_supported(H, kFlowK)) {
+      // r03: `pre` folded into the first fused WN layer.  h = (W_pre x0 + b_pre) mask = W_pre' x0' with
+      // x0' = [x0 ; mask ; 0 ..] (Cin' = half + 1 channels padded to a multiple of 8) and W_pre' = [W_pre | b_pre | 0 ..]
+      // (input channels in the physical order of the half, the Flip folded as in F.pre).  The gate conv of layer 0
+      // is linear in h, so it runs on x0' with W_in0[tap] W_pre' (composed in fp64): 13 channel groups per tap instead of 24.
+      const int Cp = (int)align_up((size_t)half + 1, 8);
+      F.Gi = Cp / 8;
+      const std::vector<float> wpre = P.dense(s + "pre");                     // [H][half][1]
+      const std::vector<float>& bpre = P.t(s + "pre.bias").data;
+      std::vector<float> wp((size_t)H * Cp, 0.f);                             // W_pre' [H][Cp]
+      for (int r = 0; r < H; ++r) {
+        for (int ci = 0; ci < half; ++ci) wp[(size_t)r * Cp + ci] = wpre[(size_t)r * half + (flipped ? half - 1 - ci : ci)];
+        wp[(size_t)r * Cp + half] = bpre[r];
+      }
+      {   // rows past H must exist and be zero: every wave runs all its tile slots over it (wn_fused.hip pre_loop)
+        const int Mrows = (int)align_up((size_t)H, 128) < 384 ? 384 : (int)align_up((size_t)H, 128);
+        std::vector<int> rws(Mrows);
+        for (int i = 0; i < Mrows; ++i) rws[i] = i < H ? i : -1;
+        F.pref = P.conv(wp, H, Cp, 1, rws, {}, nullptr, nullptr);
+      }
+      {
+        const std::vector<float> win = P.dense(s + "enc.in_layers.0");        // [2H][H][K]
+        std::vector<float> wc((size_t)2 * H * Cp * kFlowK);
+        std::vector<double> acc(Cp);
+        for (int r = 0; r < 2 * H; ++r)
+          for (int tap = 0; tap < kFlowK; ++tap) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int k = 0; k < H; ++k) {
+              const double wv = win[((size_t)r * H + k) * kFlowK + tap];
+              const float* src = &wp[(size_t)k * Cp];
+              for (int ci = 0; ci <= half; ++ci) acc[ci] += wv * src[ci];
+            }
+            for (int ci = 0; ci < Cp; ++ci) wc[((size_t)r * Cp + ci) * kFlowK + tap] = (float)acc[ci];
+          }
+        std::vector<int> rows(2 * H), brows(2 * H);                            // row order of pack_gated16
+        for (int r = 0; r < 2 * H; ++r) {
+          const int tile = r / 32, rho = r % 32;
+          const int ch = tile * 16 + (rho & 7) + 8 * (rho >> 4);
+          rows[r] = (rho & 8) ? H + ch : ch;
+          brows[r] = r;
+        }
+        F.in16f0 = P.conv(wc, 2 * H, Cp, kFlowK, rows, {}, &P.t(s + "enc.in_layers.0.bias").data, &brows);
+      }
+    }
     for (int l = 0; l < kFlowLayers; ++l) {
       char q[64];
       snprintf(q, sizeof q, "enc.in_layers.%d", l);
@@ -1137,7 +1182,8 @@ int run_decoder(mbv_model* m, const float* z, int zstride, const int* zlens, con
 // and only where the frame mask is 1 (every reader masks on load).
 // Two-launch path (MBV_WN_FUSED=0; experiments: MBV_WN_SMALL=<tiles> in the low-latency mode): gate conv,
 // then res/skip conv.
-struct WnFold { const PConv* rspf; int Cs; float* x1; int64_t x1_bstride; float sign; };
+struct WnFold { const PConv* rspf; int Cs; float* x1; int64_t x1_bstride; float sign;
+                const PConv* in16f0; const PConv* pref; int Gi; const float* x0; int in_cb; };   // in16f0 != nullptr: `pre` folded as well
 // can this WN stack take the fused one-launch-per-layer kernel (run_wn's own test; run_coupling asks before it folds `post`)
 bool wn_takes_fused(const mbv_model* m, const PConv* in_l, const PConv* in16_l, int B, int T) {
   const int H = m->cfg.hidden_channels;
@@ -1174,11 +1220,17 @@ int run_wn(mbv_model* m, const PConv* in_l, const PConv* rs_l, const PConv* in16
       WnLayerArgs a{};
       a.h_in = hin; a.h_out = hout; a.skip = skip; a.lens = lens; a.ustart = ustart; a.hmap = hmap;
       a.wg = m->W(in16_l[l].w); a.bg = m->W(in16_l[l].bias);
+      int Mg_pad = in16_l[l].Mpad;
+      if (fold && fold->in16f0 && l == 0) {          // the first layer reads the x0 half of z itself
+        a.h_in = fold->x0; a.in_cb = fold->in_cb; a.Gi = fold->Gi;
+        a.wg = m->W(fold->in16f0->w); a.bg = m->W(fold->in16f0->bias); Mg_pad = fold->in16f0->Mpad;
+        a.wpre = m->W(fold->pref->w); a.wpre_Mpad = fold->pref->Mpad;
+      }
       if (cond) { a.gcond = gc + (size_t)l * 2 * H; a.gcond_bstride = 2 * H * nl; }
       const PConv& R = fold ? fold->rspf[l] : rsp_l[l];
       a.wr = m->W(R.w); a.br = m->W(R.bias);
       a.B = B; a.H = H; a.T = T;
-      a.Mg_pad = in16_l[l].Mpad; a.Mr = R.M; a.Mr_pad = R.Mpad;
+      a.Mg_pad = Mg_pad; a.Mr = R.M; a.Mr_pad = R.Mpad;
       a.last = l == nl - 1; a.skip_accum = l > 0;
       if (fold) {
         a.Cs = fold->Cs;
@@ -1219,16 +1271,19 @@ int run_coupling(mbv_model* m, int f, bool reverse, float* z, const float* gvec,
   const bool flipped = (f % 2) == 1;
   float* x0 = flipped ? z + (size_t)half * T : z;
   float* x1 = flipped ? z : z + (size_t)half * T;
-  {
+  static const int fold_env = [] { const char* e = getenv("MBV_FLOW_FOLD"); return e ? atoi(e) : 3; }();   // bit 0: post, bit 1: pre
+  const bool fold_post = (fold_env & 1) && F.rspf[0].M && wn_takes_fused(m, F.in, F.in16, B, T);
+  const bool fold_pre = fold_post && (fold_env & 2) && F.in16f0.M && F.pref.M && wn_fused_fits(B, I, T);   // (x0 is addressed through a whole-tensor view of z)
+  if (!fold_pre) {
     ConvArgs a = conv_args(m, F.pre, x0, bsI, T, hbuf, bsH, T, B);
     a.out_lens = lens;
     launch_conv1d(a, s);
   }
-  static const int fold_env = [] { const char* e = getenv("MBV_FLOW_FOLD"); return e ? atoi(e) : 1; }();
-  if (fold_env && F.rspf[0].M && wn_takes_fused(m, F.in, F.in16, B, T)) {
+  if (fold_post) {
     // `post` lives in the res/skip convs (do_finalize): the last WN layer applies the coupling on the valid frames.
     // Frames at and beyond lens[b] are not touched: z arrives masked (expand_kernel / posterior_sample) and stays so.
-    const WnFold fold{F.rspf, half, x1, bsI, reverse ? -1.f : 1.f};
+    const WnFold fold{F.rspf, half, x1, bsI, reverse ? -1.f : 1.f,
+                      fold_pre ? &F.in16f0 : nullptr, fold_pre ? &F.pref : nullptr, F.Gi, x0, I};
     return run_wn(m, F.in, F.rs, F.in16, F.rsp, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, ustart, lens, B, T, s, &fold);
   }
   run_wn(m, F.in, F.rs, F.in16, F.rsp, kFlowLayers, F.cw, F.cb, gvec, hbuf, acts, skip, gc, ustart, lens, B, T, s);

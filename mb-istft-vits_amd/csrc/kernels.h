@@ -121,6 +121,15 @@ struct WnLayerArgs {
   // r03: the coupling layer's 1x1 `post` conv (modules.py:346-350) folded into the res/skip convs: their skip rows are
   // W_post . W_rs[skip rows] (Cs = I/2 rows instead of H), so `skip` accumulates m = post(sum of skips) directly and
   // the LAST layer applies the coupling x1 = (x1 + couple_sign * m) on its valid frames instead of storing skip.
+  // r03, first layer of a coupling only: the 1x1 `pre` conv (modules.py:339) folded in as well.  h = (W_pre x0 + b) mask
+  // is linear in x0' = [x0 ; mask] (Cin' = I/2 + 1 channels, padded to 8 Gi), so the gate conv runs on x0' directly with
+  // the composite weights W_in[tap] W_pre' (K-loop of Gi instead of H/8 groups: 13 instead of 24) and the residual rows
+  // start from W_pre' x0'(t) computed as one more K-block of the res/skip GEMM (wpre: rows H, padded to >= 128 NRT).
+  // h_in then is the x0 half of z: in_cb channels per utterance, the first 8 (Gi - 1) rows real, group Gi - 1 = the mask.
+  int Gi;                  // input channel groups of the gate conv / the window; 0: H / 8
+  int in_cb;               // channel rows per utterance of h_in; 0: H
+  const float* wpre;       // W_pre' packed like every conv (Cin = 8 Gi, natural channel order), or nullptr
+  int wpre_Mpad;
   int Cs;                  // channels of `skip` ([B, Cs, T]); 0: H (unfolded)
   float* x1;               // last layer only: the half of z the coupling updates, [B, x1_bstride / T ..] rows Cs; nullptr: store skip
   int64_t x1_bstride;      // elements between utterances of x1 (I * T)

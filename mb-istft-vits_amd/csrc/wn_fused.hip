@@ -126,6 +126,9 @@ struct WnCtx {
   int couple;                    // last layer applies x1 += sign * (skip + rs) instead of storing skip
   int xoff;                      // lane's column in the input-window image: half * kXS + (l31 & 15)
   int G, H, Mr, wave, hl, l31, last, skip_accum, exact_gate;
+  int Gi;                        // input groups of the gate conv (== G unless `pre` is folded in)
+  int prefold;                   // the window holds x0' = [x0 ; mask], not h: residual rows start from the wpre K-block
+  __amdgpu_buffer_rsrc_t wp_rs; unsigned wp_voff, wp_step;
 };
 
 // A ring of the gate GEMM: slot = tap; the load for step s + kDG (s = g * 5 + tap) is issued at step s
@@ -139,7 +142,7 @@ __device__ __forceinline__ void gate_ring_init(f32x4 (&ra)[kK][NRT], const WnCtx
 #pragma unroll
   for (int tap = 0; tap < kDG; ++tap)
 #pragma unroll
-    for (int j = 0; j < NRT; ++j) ra[tap][j] = bload4(c.wg_rs, c.wg_voff, (unsigned)(tap * c.G) * c.wg_step + j * 2048u);
+    for (int j = 0; j < NRT; ++j) ra[tap][j] = bload4(c.wg_rs, c.wg_voff, (unsigned)(tap * c.Gi) * c.wg_step + j * 2048u);
 }
 
 // gate accumulators start from bias (+ speaker conditioning).  Packed row (r, hl) of tile
@@ -165,7 +168,7 @@ __device__ __forceinline__ void gate_acc_init(f32x16 (&acc)[NRT], const WnCtx& c
 template <int NRT>
 __device__ __forceinline__ void gate_loop(f32x16 (&acc)[NRT], f32x4 (&ra)[kK][NRT], const f32x4* Xs, const WnCtx& c) {
   const f32x4* xl = Xs + c.hl * kXL + c.xoff;
-  const int G = c.G;
+  const int G = c.Gi;
   f32x4 bv = xl[0];
   for (int g = 0; g < G; ++g) {
     const int gn = g + 1 < G ? g + 1 : g;      // past the end: re-load the last group (unused)
@@ -241,8 +244,10 @@ __device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const f32x4* Xs,
         float v = bq[s];
         if (row0 < c.Mr) {                                      // (an idle tile slot: see rs_store)
           if (is_res) {
-            const int ch = row0 + 8 * q + 4 * c.hl + s;         // (ch & 7) = 4 hl + s
-            v += xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
+            if (!c.prefold) {
+              const int ch = row0 + 8 * q + 4 * c.hl + s;       // (ch & 7) = 4 hl + s
+              v += xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
+            }
           } else if (c.skip_accum) {
             v += bload1(c.skip_rs, c.sk_voff, (srow0 + 8 * q + s) * c.rowT);
           }
@@ -277,6 +282,43 @@ __device__ __forceinline__ void rs_loop(f32x16 (&acr)[NRT], f32x4 (&rb)[kDR][NRT
           acr[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[d][j][s4], bv[s4], acr[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       bv = bn;
+    }
+  }
+}
+
+// folded `pre`: acr += W_pre' . x0'(t) — the residual rows' start values h(t) as one more K-block (Gi groups) of the
+// res/skip GEMM.  B operand = the centre column of the input window (tap (K - 1) / 2 of the gate loop's reads); A =
+// wpre, whose rows past H are zero padding (>= 128 NRT rows are allocated), so the skip tiles just add zeros.
+template <int NRT>
+__device__ __forceinline__ void pre_loop(f32x16 (&acr)[NRT], f32x4 (&rb)[kDR][NRT], const f32x4* Xs, const WnCtx& c) {
+  const f32x4* xl = Xs + c.hl * kXL + c.xoff + (kK - 1) / 2;
+  const int G = c.Gi;
+#pragma unroll
+  for (int d = 0; d < kDR - 1; ++d)
+#pragma unroll
+    for (int j = 0; j < NRT; ++j) rb[d][j] = bload4(c.wp_rs, c.wp_voff, (unsigned)(d < G ? d : G - 1) * c.wp_step + j * 2048u);
+  f32x4 bv = xl[0];
+  for (int g0 = 0; g0 < G; g0 += kDR) {
+#pragma unroll
+    for (int d = 0; d < kDR; ++d) {
+      const int g = g0 + d;
+      if (g < G) {                              // (G = 13 is not a multiple of the ring depth; wave-uniform)
+        {
+          const int gl = g + kDR - 1 < G ? g + kDR - 1 : G - 1;
+#pragma unroll
+          for (int j = 0; j < NRT; ++j) rb[(d + kDR - 1) % kDR][j] = bload4(c.wp_rs, c.wp_voff, (unsigned)gl * c.wp_step + j * 2048u);
+        }
+        const int gb = g + 1 < G ? g + 1 : g;
+        const f32x4 bn = xl[gb * 2 * kXL];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int j = 0; j < NRT; ++j)
+            acr[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[d][j][s4], bv[s4], acr[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bv = bn;
+      }
     }
   }
 }
@@ -323,14 +365,21 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   c.hl = lane >> 5; c.l31 = lane & 31;
   const int H = a.H, T = a.T;
   c.H = H; c.G = H / 8; c.Mr = a.Mr; c.last = a.last; c.skip_accum = a.skip_accum; c.exact_gate = a.debug == 2;
-  const int G = c.G;                           // 8-channel groups (4 K-steps each)
-  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [G][2][kXL]
-  f32x4* const As = Xs + G * 2 * kXL;                        // [G][2][32]
+  const int G = c.G;                           // 8-channel groups (4 K-steps each) of the gated tile
+  c.Gi = a.Gi ? a.Gi : G;
+  c.prefold = a.wpre != nullptr;
+  const int Gi = c.Gi;                         // ... of the input window
+  const int in_cb = a.in_cb ? a.in_cb : H;
+  f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [Gi][2][kXL]
+  f32x4* const As = Xs + Gi * 2 * kXL;                       // [G][2][32]
   const int Hn = a.ustart[a.B];                // half-units of the batch
   const int U = (Hn + 1) / 2;                  // tiles
 
   // packed weights W[step][h][Mpad][4 floats], step = tap * G + g: lane offset + scalar step offset
-  c.wg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg), 0, kK * H * a.Mg_pad * 4, kRsrcFlags);
+  c.wg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wg), 0, kK * 8 * Gi * a.Mg_pad * 4, kRsrcFlags);
+  c.wp_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpre), 0, a.wpre ? 8 * Gi * a.wpre_Mpad * 4 : 0, kRsrcFlags);
+  c.wp_voff = (unsigned)((c.hl * a.wpre_Mpad + c.wave * 32 + c.l31) * 16);
+  c.wp_step = (unsigned)(2 * a.wpre_Mpad * 16);
   c.wr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wr), 0, H * a.Mr_pad * 4, kRsrcFlags);
   c.bg_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bg), 0, 2 * H * 4, kRsrcFlags);
   c.br_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.br), 0, a.Mr * 4, kRsrcFlags);
@@ -342,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   // whole-tensor views (the launcher checks B H T 4 < 2^32): the two halves of a tile may belong to
   // different utterances, so the utterance goes into the lane offset
   const unsigned all_bytes = (unsigned)a.B * (unsigned)H * c.rowT;
-  c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in), 0, all_bytes, kRsrcFlags);
+  c.hin_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in), 0, (unsigned)a.B * (unsigned)in_cb * c.rowT, kRsrcFlags);
   c.hout_rs = __builtin_amdgcn_make_buffer_rsrc(a.h_out, 0, a.last ? 0 : all_bytes, kRsrcFlags);
   const int Cs = a.Cs ? a.Cs : H;
   c.skip_rs = __builtin_amdgcn_make_buffer_rsrc(a.skip, 0, (unsigned)a.B * (unsigned)Cs * c.rowT, kRsrcFlags);
@@ -391,10 +440,12 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
       const int k = cc >= kXS, c2 = cc - k * kXS;
       const int ti = (k ? ht0[1] : ht0[0]) - (kK - 1) / 2 + c2;
       const int b = k ? hb[1] : hb[0];
-      const bool ok = P < 2 * G && c2 < kXW && ti >= 0 && ti < (k ? hlen[1] : hlen[0]);
-      const unsigned vo = ok ? (unsigned)((b * H + (P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
+      const bool ok = P < 2 * Gi && c2 < kXW && ti >= 0 && ti < (k ? hlen[1] : hlen[0]);
+      const bool mrow = c.prefold && (P >> 1) == Gi - 1;                 // the mask group of x0' (no memory behind it)
+      const unsigned vo = ok && !mrow ? (unsigned)((b * in_cb + (P >> 1) * 8 + (P & 1)) * T + ti) * 4u : kOob;
       xw[i][0] = bload1(c.hin_rs, vo, 0); xw[i][1] = bload1(c.hin_rs, vo, 2 * c.rowT);
       xw[i][2] = bload1(c.hin_rs, vo, 4 * c.rowT); xw[i][3] = bload1(c.hin_rs, vo, 6 * c.rowT);
+      if (mrow && ok && (P & 1) == 0) xw[i][0] = 1.f;                    // channel 8 (Gi - 1) = the frame mask
     }
     f32x16 acc[NRT];
     gate_acc_init<NRT>(acc, c, a.gcond != nullptr);
@@ -402,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int e = tid + 256 * i;
-      if (e < G * 2 * kXL) Xs[e] = xw[i];
+      if (e < Gi * 2 * kXL) Xs[e] = xw[i];
     }
     __syncthreads();
 
@@ -416,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
     __syncthreads();
 
     rs_loop<NRT>(acr, rb, As, c);
+    if (c.prefold) pre_loop<NRT>(acr, rb, Xs, c);
     rs_store<NRT>(acr, c);
   }
 }
@@ -428,8 +480,8 @@ bool wn_fused_supported(int H, int K) {
 }
 
 void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
-  const int G = a.H / 8;
-  const size_t lds_bytes = (size_t)(G * 2 * kXL + G * 2 * 32) * 16;
+  const int G = a.H / 8, Gi = a.Gi ? a.Gi : G;
+  const size_t lds_bytes = (size_t)(Gi * 2 * kXL + G * 2 * 32) * 16;
   const int nrt = (2 * a.H / 32 + 3) / 4;
   WnLayerArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_WN_DEBUG_A"); return e ? atoi(e) : 0; }();
