@@ -290,3 +290,11 @@ print("BOUND-OK")
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "BOUND-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_integration_md_quotes_the_shipped_binding_verbatim():
+    """INTEGRATION.md section B is the text of mb-istft-vits_amd/reference_binding.py (scripts/sync_integration_md.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "sync_integration_md.py"), "--check"])
+    assert r.returncode == 0, "INTEGRATION.md section B is stale: run python scripts/sync_integration_md.py"
