@@ -14,6 +14,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* in, unsigne
   const bool worker = worker_hi ? wave >= 4 : wave < 4;
   sm[tid] = f32x4{1.f, 2.f, 3.f, 4.f};
   __syncthreads();
+  const unsigned long long t_start = __builtin_readcyclecounter();
   if (!worker) {
     if (!mfma_on) return;
     f32x16 acc[6];
@@ -46,6 +47,45 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* in, unsigne
         for (int q = 0; q < 5; ++q) sink += r0[q][0];
       }
       acc[0][0] += sink;
+    } else if constexpr (READS == 4 || READS == 5 || READS == 6) {
+      // 4: as 1, but every LDS result is copied (v_mov) before an MFMA reads it
+      // 5: as 1 with ONE ds_read_b128 per step (its four values feed all 24 MFMAs)
+      // 6: as 1, reads issued TWO steps ahead (three register sets)
+      const f32x4* base = sm + (tid & 63) + (wave & 3) * 64;
+      constexpr int NR = READS == 5 ? 1 : 5;
+      f32x4 r0[5], r1[5], r2[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) { r0[q] = base[(q % NR) * 256]; r1[q] = base[(q % NR) * 256 + 64]; r2[q] = r0[q]; }
+      for (int it = 0; it < mfma_iters; ++it) {
+        f32x4 use[5];
+        if constexpr (READS == 6) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) r2[q] = base[q * 256 + ((it + 2) & 3) * 64];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) use[q] = r0[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) r1[q] = base[q * 256 + ((it + 1) & 3) * 64];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            use[q] = r0[q % NR];
+            if constexpr (READS == 4) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(use[q][0]), "+v"(use[q][1]), "+v"(use[q][2]), "+v"(use[q][3]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int n = 0; n < 6; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(use[n % 2][u], use[2 + n % 3][u], acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (READS == 6) {
+#pragma unroll
+          for (int q = 0; q < 5; ++q) { r0[q] = r1[q]; r1[q] = r2[q]; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) r0[q] = r1[q];
+        }
+      }
     } else if constexpr (READS == 1) {
       // the conv kernel's step: 5 ds_read_b128 prefetched one step ahead + 24 MFMAs
       const f32x4* base = sm + (tid & 63) + (wave & 3) * 64;
@@ -81,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* in, unsigne
     float s = 0;
     for (int n = 0; n < 6; ++n) for (int r = 0; r < 16; ++r) s += acc[n][r];
     out[blockIdx.x * 512 + tid] = s;
+    if ((tid & 63) == 0) cyc[blockIdx.x * 8 + wave] = __builtin_readcyclecounter() - t_start;
     return;
   }
   // worker: let the partner get going, then time N instructions
@@ -132,10 +173,16 @@ static void run(const char* what, int n_inst) {
         k<KIND, READS><<<256, 512>>>(out, in, cyc, 3000, worker_hi, prio, mfma_on);
         (void)hipDeviceSynchronize();
         unsigned long long h[256 * 8]; (void)hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
-        double sum = 0; int n = 0;
-        for (int i = 0; i < 256 * 8; ++i) if (h[i]) { sum += h[i]; ++n; }
-        printf("%-34s partner %-12s worker = %-26s prio %d: %7.0f cycles for %d instructions = %6.1f per instruction\n", what,
+        double sum = 0, psum = 0; int n = 0, pn = 0;
+        for (int i = 0; i < 256 * 8; ++i) {
+          const bool is_worker = worker_hi ? (i & 7) >= 4 : (i & 7) < 4;
+          if (!h[i]) continue;
+          if (is_worker) { sum += h[i]; ++n; } else { psum += h[i]; ++pn; }
+        }
+        printf("%-34s partner %-12s worker = %-26s prio %d: %7.0f cycles for %d instructions = %6.1f per instruction", what,
                mfma_on ? "MFMA stream" : "absent", worker_hi ? "waves 4-7 (younger)" : "waves 0-3 (older)", prio * 3, sum / n, n_inst, sum / n / n_inst);
+        if (pn) printf("   | partner: %.1f cycles per MFMA", psum / pn / (3000.0 * 24));
+        printf("\n");
       }
 }
 int main() {
@@ -147,6 +194,15 @@ int main() {
   run<0, 1>("v_fma_f32 (independent)", 256);
   run<1, 1>("ds_write_b128 (+ final wait)", 64);
   run<2, 1>("global_load_dword (+ final wait)", 64);
+  printf("---- partner = conv step loop, every LDS result copied by v_mov before its MFMAs\n");
+  run<0, 4>("v_fma_f32 (independent)", 256);
+  run<2, 4>("global_load_dword (+ final wait)", 64);
+  printf("---- partner = conv step loop with ONE ds_read_b128 per step\n");
+  run<0, 5>("v_fma_f32 (independent)", 256);
+  run<2, 5>("global_load_dword (+ final wait)", 64);
+  printf("---- partner = conv step loop, reads issued two steps ahead\n");
+  run<0, 6>("v_fma_f32 (independent)", 256);
+  run<2, 6>("global_load_dword (+ final wait)", 64);
   printf("---- partner = MFMA only, source registers rotating over 8 + 8\n");
   run<0, 2>("v_fma_f32 (independent)", 256);
   run<2, 2>("global_load_dword (+ final wait)", 64);
