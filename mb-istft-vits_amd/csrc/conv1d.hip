@@ -215,13 +215,17 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
 // with one workgroup per CU it used to run with the matrix pipe idle: measured 25 % of a k=3 conv)
 // is then followed immediately by MFMA work on data already in LDS, so its stores drain underneath.
 // No staging registers are live across the epilogue.
-template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0>
-__global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
-                                                                   int tiles_y, int total_tiles,
-                                                                   int ksplit) {
-  constexpr int NT = 128 * NWN;          // threads
+// NWM (r03) = waves along the rows: 2 everywhere except the 64 x 384 shape (NWM = 1, NWN = 4: 256 threads, the same
+// 2 x 3 MFMA tiles per wave and double-buffered staging as the 128 x 384 shape, two workgroups per CU) that serves
+// convs with <= 64 output rows — the mini configurations' 64-channel stage — instead of the 64 x 128 shape's two
+// accumulators per wave.
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
+                                                                        int tiles_y, int total_tiles,
+                                                                        int ksplit) {
+  constexpr int NT = 64 * NWM * NWN;     // threads
   constexpr bool DB = NWN == 4;          // double-buffered LDS
-  constexpr int BM = 64 * WM;            // 2 waves x WM tiles of 32 rows
+  constexpr int BM = 32 * WM * NWM;      // NWM waves x WM tiles of 32 rows
   constexpr int BN = 32 * WN * NWN;      // NWN waves x WN tiles of 32 columns
   constexpr int G = CK / 8;              // channel groups (4 K-steps each) per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
   // Only the CK = 8 kernels (k = 7 / 11): their MFMA loop (9 - 14 us) covers the DMA issued at its top.
   // With CK = 16 (k = 3, 4 us per chunk) the same change measured +5 % (489 -> 516 us): register staging
   // issues a chunk's weights one barrier EARLIER and so has two loops to land them.
-  constexpr bool GLDS = DB && CK <= MBV_CONV_GLDS;
+  constexpr bool GLDS = DB && (CK <= MBV_CONV_GLDS || NWM == 1);   // (NWM = 1: twice the window items per thread, no room for wreg)
   f32x4 wreg[GLDS ? 1 : NW];
   f32x4 xreg[NXP];
   int xoff[NXP];
@@ -856,9 +860,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void conv1d_mfma_kernel(const ConvArg
 #undef MBV_GLDS_DRAIN
 }
 
-template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0>
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2>
 static void launch_epi(const ConvArgs& a, hipStream_t s) {
-  constexpr int BM = 64 * WM, BN = 32 * WN * NWN, G = CK / 8;
+  constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, G = CK / 8, NT = 64 * NWM * NWN;
   const int XL = BN + (a.K - 1) * a.dil;
   // float4 units per buffer: input image + weight slab + one step of padding for the operand
   // prefetch overrun; two buffers for the 512-thread variant
@@ -869,7 +873,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   // persistent tiles: at most the workgroups that are resident at once (1 per CU for the
   // 512-thread shape, 2 for the 256-thread one: both are register-limited to 2 waves / SIMD)
   static const int persist = [] { const char* e = getenv("MBV_CONV_PERSIST"); return e ? atoi(e) : 1; }();
-  const long slots = 256L * (NWN == 4 ? 1 : 2);
+  const long slots = 256L * (NT == 512 ? 1 : 2);
   // Split-K for launches that fill less than a quarter of the chip (single utterances: 34 tiles of a
   // 128-channel decoder conv at batch 1): at least two chunks per split, workspace and ticket
   // counters permitting.  OPT-IN (mbv_set_option("splitk", 1) or MBV_CONV_SPLITK=1: the low-latency service setting): the order of
@@ -903,7 +907,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   a2.debug = dbg;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
 #ifdef MBV_CONV_STAMPS
                               150 * 1024);                        // static LDS: the ticket + 8 KB of stamps
@@ -912,7 +916,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
 #endif
     attr = true;
   }
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC>), dim3(grid), dim3(128 * NWN), lds_bytes, s, a2,
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM>), dim3(grid), dim3(NT), lds_bytes, s, a2,
                      tiles_x, tiles_y, (int)total, S);
 }
 
@@ -1084,6 +1088,30 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
     if (big) launch_ck<2, 3, 4>(a, s);
     else launch_ck<2, 2, 2>(a, s);
   } else {
+    // <= 64 output rows: the 64 x 384 shape when the launch fills its 512 half-CU slots (exact fp32, K > 1, the
+    // decoder's epilogues); else 64 x 128.  Same chain of operations per output element either way.
+    static const int half_on = [] { const char* e = getenv("MBV_CONV_HALF"); return e ? atoi(e) : 1; }();
+    if (half_on && mode >= 3 && a.T >= 384 && a.K > 1 && a.prec != 3 && !a.splitk && !a.trim_map &&
+        (long)((a.T + 383) / 384) * a.B >= 512 && a.T / (double)(((a.T + 383) / 384) * 384) >= 0.90 * a.T / (double)(((a.T + 127) / 128) * 128)) {
+      const bool ck16 = a.K <= 5 && (a.K - 1) * a.dil <= 24;
+      bool done = true;
+      if (ck16) {
+        switch (a.epi) {
+          case EPI_STORE: launch_epi<2, 3, 16, 4, EPI_STORE, 0, 1>(a, s); break;
+          case EPI_RESID: launch_epi<2, 3, 16, 4, EPI_RESID, 0, 1>(a, s); break;
+          case EPI_RESID_ACC: launch_epi<2, 3, 16, 4, EPI_RESID_ACC, 0, 1>(a, s); break;
+          default: done = false;
+        }
+      } else {
+        switch (a.epi) {
+          case EPI_STORE: launch_epi<2, 3, 8, 4, EPI_STORE, 0, 1>(a, s); break;
+          case EPI_RESID: launch_epi<2, 3, 8, 4, EPI_RESID, 0, 1>(a, s); break;
+          case EPI_RESID_ACC: launch_epi<2, 3, 8, 4, EPI_RESID_ACC, 0, 1>(a, s); break;
+          default: done = false;
+        }
+      }
+      if (done) return;
+    }
     launch_ck<1, 2, 2>(a, s);
   }
 }
