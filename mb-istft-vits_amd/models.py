@@ -364,10 +364,12 @@ class SynthesizerTrn(nn.Module):
             if prior_rows is not None:
                 # sharded run: the draw of the WHOLE batch, this shard's rows — also at noise_scale == 0, so that
                 # the device generator advances exactly as in a single-process run of the full batch (a later
-                # noisy call in the same process then still reproduces the single-process draws).  Cost: the
-                # RNG kernel over B_global x I x T' (222 MB at 8 x 64 utterances, ~0.1 ms) per call.
+                # noisy call in the same process then still reproduces the single-process draws).  Large draws take
+                # only the Philox calls that hold the shard's rows (rows_of_randn.py, verified against the full draw
+                # on first use), so the cost does not grow with the world size.
                 r_lo, r_hi, b_all = prior_rows
-                noise = torch.randn(b_all, I, Tp, device=dev, dtype=torch.float32)[r_lo:r_hi]
+                from .rows_of_randn import randn_rows       # own rows of the full-batch draw, generator state included
+                noise = randn_rows(r_lo, r_hi, b_all, (I, Tp), dev)
                 noise = noise.contiguous() if float(noise_scale) != 0.0 else None
             else:
                 noise = torch.randn(B, I, Tp, device=dev, dtype=torch.float32)

@@ -118,3 +118,22 @@ def test_bench_self_launch_two_ranks_rehearsal(tmp_path):
     if torch.cuda.device_count() < 2:
         assert j["dist"]["rehearsal"] and j["dist"]["backend"] == "gloo"
     assert j["value"] > 0
+
+
+def test_rows_of_a_full_batch_draw_without_the_full_draw():
+    """`rows_of_randn.randn_rows` == `torch.randn(b_all, I, T')[lo:hi]` bitwise, generator state included, through the
+    partial-draw path (verified against the full draw on first use) — the sharded path's prior noise at 8 x 64."""
+    from mb_istft_vits_amd import rows_of_randn as rr
+    dev = torch.device("cuda", 0)
+    rr._ok.clear()
+    for b_all, lo, hi, tail in ((512, 64, 128, (192, 566)), (512, 448, 512, (192, 523)), (256, 0, 32, (192, 301)), (8, 2, 4, (192, 40))):
+        for rep in range(2):                      # first use verifies, second takes the fast path
+            torch.cuda.manual_seed(1234 + rep)
+            want = torch.randn(b_all, *tail, device=dev)[lo:hi].clone()
+            after = torch.randn(5, device=dev).clone()
+            torch.cuda.manual_seed(1234 + rep)
+            got = rr.randn_rows(lo, hi, b_all, tail, dev)
+            after2 = torch.randn(5, device=dev)
+            assert torch.equal(got, want), (b_all, lo, hi, rep)
+            assert torch.equal(after, after2), "generator left elsewhere than the full draw leaves it"
+    assert rr._ok.get(0) is True, "the partial-draw path was not verified on this torch build (it falls back to the full draw)"
