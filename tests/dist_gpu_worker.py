@@ -84,6 +84,7 @@ def main():
                                              outputs=None)
                 torch.cuda.synchronize()
                 res["overlap_halves_equal"] = bool(torch.equal(o4, o) and torch.equal(y4, ylen))
+                res["overlap_halves_maxdiff"] = float((o4 - o).abs().max())
                 res["timing_halves"] = tm.ms()
                 tm = mdist.StepTimes()
                 mdist.sharded_infer(net, xg, xlg, sidg, noise_scale=0, length_scale=1, timing=tm)

@@ -54,7 +54,11 @@ def test_two_rank_hip_sharded_infer_equals_full_batch(tmp_path):
     for r in res:
         assert r["bad_token"] == "IndexError" and r["small_batch"] == "ValueError"
         assert r["after_errors_equal"] and r["mini_b5_all_outputs_equal"]
-        assert r["overlap_next_equal"] and r["overlap_halves_equal"]
+        assert r["overlap_next_equal"]
+        if os.environ.get("MBV_CONV_SPLITK", "0") not in ("", "0"):
+            assert r["overlap_halves_maxdiff"] < 2e-5      # low-latency mode: kernels picked by launch size, equal within rounding
+        else:
+            assert r["overlap_halves_equal"]
         assert r["mini_b5_arena_floats"] == res[0]["mini_b5_arena_floats"] > 0
         for k in ("timing_plain", "timing_next", "timing_halves"):
             t = r[k]
