@@ -655,7 +655,8 @@ def test_trimmed_decode_is_bitwise_the_default_on_valid_samples():
         for b in range(B):
             n = min(int(ylen[b]) * spf, o_ref.shape[-1])
             assert torch.equal(o_trim[b, 0, :n], o_ref[b, 0, :n]), (cfg_name, b)
-            assert not bool(o_trim[b, 0, n:].any()), (cfg_name, b)
+            if os.environ.get("MBV_CONV_SPLITK", "0") in ("", "0"):      # (the low-latency mode ignores the option: full decode)
+                assert not bool(o_trim[b, 0, n:].any()), (cfg_name, b)
         assert int(ylen.min()) < int(ylen.max())          # the batch really is ragged
         # the default is untouched by the option having been used
         o_again = net.infer(xg, xlg, sg, noise_scale=0, length_scale=1, outputs=("o",), max_len=ml)[0]
