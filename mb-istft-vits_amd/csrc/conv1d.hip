@@ -433,6 +433,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
     }                                                                                        \
   }
 
+  // (experiment, MBV_CONV_START_STAGGER via a.debug >> 8: workgroups start (blockIdx & 7) x that many s_sleep(127)s apart,
+  // so that their tile rounds — the start-value load bursts and the epilogue store bursts — stop coinciding)
+  if constexpr (DB) {
+    const int stg = a.debug >> 8;
+    for (int i = (int)(blockIdx.x & 7) * stg; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- prime: chunk 0 of the first tile -> LDS buffer 0 -------------------------
   MBV_ISSUE_NEXT();
   {
@@ -904,7 +910,8 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   const int grid = (int)((persist && units > slots) ? slots : units);
   ConvArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
-  a2.debug = dbg;
+  static const int stg = [] { const char* e = getenv("MBV_CONV_START_STAGGER"); return e ? atoi(e) : 0; }();
+  a2.debug = dbg | (stg << 8);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM>),
