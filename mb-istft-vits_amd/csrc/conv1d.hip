@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
   // (experiment, MBV_CONV_START_STAGGER via a.debug >> 8: workgroups start (blockIdx & 7) x that many s_sleep(127)s apart,
   // so that their tile rounds — the start-value load bursts and the epilogue store bursts — stop coinciding)
   if constexpr (DB) {
-    const int stg = a.debug >> 8;
+    const int stg = (a.debug >> 8) & 0xff;
     for (int i = (int)(blockIdx.x & 7) * stg; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   }
   // ---- prime: chunk 0 of the first tile -> LDS buffer 0 -------------------------
