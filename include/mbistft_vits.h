@@ -265,6 +265,12 @@ int mbv_pcm16(mbv_model *m, const float *wave, const int64_t *y_lengths, int B, 
 int64_t mbv_read_stage(mbv_model *m, const char *name, float *dst, int64_t capacity,
                        void *stream);
 
+/* The text encoder's windowed relative-position attention by itself (tests; attentions.py:148-243):
+ * qkv DEVICE [B, 3H, T] (q | k | v as the fused projection leaves them), emb_k / emb_v DEVICE [9, H / n_heads]
+ * (heads share), lengths DEVICE int64 [B], o DEVICE [B, H, T].  Synchronises the stream. */
+int mbv_op_rel_attention(mbv_model *m, const float *qkv, const float *emb_k, const float *emb_v,
+                         const int64_t *lengths, float *o, int B, int H, int n_heads, int T, void *stream);
+
 /* Generic conv1d through the MFMA kernel (tests): y = conv(x, w) + bias,
  * 'same' padding.  w HOST [Cout, Cin, K], bias HOST [Cout] or NULL,
  * x/y DEVICE [B, Cin, T] / [B, Cout, T]; in_slope: leaky-relu slope applied

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mbv_finalize_weights", "mbv_missing_weights", "mbv_encode", "mbv_synthesize", "mbv_decode",
     "mbv_speaker_embedding", "mbv_stage_times_ms", "mbv_istft_pqmf", "mbv_read_stage",
     "mbv_op_conv1d", "mbv_kernel_times_ms", "mbv_istft_finalize", "mbv_pcm16", "mbv_voice_conversion",
-    "mbv_set_option", "mbv_arena_floats", "mbv_export_arena", "mbv_import_arena", "mbv_ticket", "mbv_stage_times_ms_at",
+    "mbv_set_option", "mbv_arena_floats", "mbv_export_arena", "mbv_import_arena", "mbv_ticket", "mbv_stage_times_ms_at", "mbv_op_rel_attention",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
     L.mbv_import_arena.argtypes = [vp, vp, C.c_int64, vp]
     L.mbv_read_stage.argtypes = [vp, C.c_char_p, vp, C.c_int64, vp]
     L.mbv_read_stage.restype = C.c_int64
+    L.mbv_op_rel_attention.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mbv_op_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, vp]
     for s in SYMBOLS:
         getattr(L, s)          # AttributeError if the header and the library ever drift

@@ -2017,6 +2017,24 @@ int64_t mbv_read_stage(mbv_model* m, const char* name, float* dst, int64_t capac
   return numel;
 }
 
+int mbv_op_rel_attention(mbv_model* m, const float* qkv, const float* emb_k, const float* emb_v, const int64_t* lengths,
+                         float* o, int B, int H, int n_heads, int T, void* stream) {
+  if (!m) return 1;
+  if (!qkv || !emb_k || !emb_v || !lengths || !o || B <= 0 || T <= 0 || n_heads <= 0 || H % n_heads || (H / n_heads) % 2 || H / n_heads > 96)
+    return m->fail("mbv_op_rel_attention: bad arguments (head dimension must be even and <= 96)");
+  DEVICE_GUARD(m);
+  hipStream_t s = (hipStream_t)stream;
+  int* lens32 = nullptr;
+  HIPCHK(m, hipMalloc((void**)&lens32, (size_t)B * sizeof(int) * 2));
+  launch_lens_to_i32(lengths, lens32, B, T, lens32 + B, s);
+  launch_rel_attention(qkv, emb_k, emb_v, lens32, o, B, H, n_heads, T, s);
+  const hipError_t e = hipStreamSynchronize(s);
+  (void)hipFree(lens32);
+  HIPCHK(m, e);
+  HIPCHK(m, hipGetLastError());
+  return 0;
+}
+
 int mbv_op_conv1d(mbv_model* m, const float* x, const float* w_host, const float* bias_host, float* y,
                   int B, int Cin, int Cout, int T, int K, int dilation, float in_slope, void* stream) {
   if (!m) return 1;

@@ -438,3 +438,37 @@ def test_fused_wn_layer_kernel_against_cpu_loop(tmp_path):
                  ["5", "192", "70", "0"], ["3", "64", "33", "0"], ["4", "160", "50", "1"], ["2", "96", "74", "0", "61", "74"]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (args, r.stdout[-1500:], r.stderr[-500:])
+
+
+def test_rel_attention_kernel_against_the_oracle_op():
+    """`rel_attention_kernel` on its own (the attention was only covered through x_enc and the durations):
+    random q | k | v and relative embeddings, ragged lengths incl. a 1-token and a full-length utterance, T across the
+    32-key tile boundaries, head dimensions 96 and 48 — against the oracle's `relative_attention` (attentions.py:148-243
+    restated: -1e4 mask fill, window of +-4, q scaled before both the content and the relative logits)."""
+    import ctypes as C
+    from gpu_util import make_net, ptr
+    from mb_istft_vits_amd import _capi
+    from oracle import ref_infer as R
+    net = make_net("ljs_mini_mb_istft_vits")[0]
+    h = net._ensure_handle()
+    g = torch.Generator().manual_seed(7)
+    for (B, H, heads, T) in ((3, 192, 2, 200), (2, 96, 2, 33), (4, 192, 2, 64), (1, 192, 2, 1), (2, 192, 2, 257)):
+        d = H // heads
+        qkv = torch.randn(B, 3 * H, T, generator=g)
+        ek, ev = torch.randn(9, d, generator=g) * 0.3, torch.randn(9, d, generator=g) * 0.3
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        if B > 1:
+            lens[1] = 1
+        o = torch.empty(B, H, T, device="cuda")
+        dq, dk, dv, dl = qkv.cuda(), ek.cuda(), ev.cuda(), lens.cuda()        # (kept alive across the call)
+        rc = _capi.lib().mbv_op_rel_attention(h, ptr(dq), ptr(dk), ptr(dv), ptr(dl), ptr(o), B, H, heads, T, net._stream())
+        _capi.check(h, rc, "mbv_op_rel_attention")
+        mask = (torch.arange(T)[None, :] < lens[:, None]).float()
+        want = R.relative_attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], mask, ek, ev, heads)
+        got = o.cpu()
+        for b in range(B):                       # valid queries only (the encoder masks the rest right behind the attention)
+            n = int(lens[b])
+            err = float((got[b, :, :n] - want[b, :, :n]).abs().max())
+            ref = float(want[b, :, :n].abs().max())
+            assert err <= 2e-5 * max(ref, 1.0), (B, H, T, b, err, ref)
