@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MBV_ABI_VERSION 2
+#define MBV_ABI_VERSION 3   /* 3 (r03): + arena export / import, call tickets, option "trim", mbv_op_rel_attention; structs unchanged */
 
 #define MBV_DEC_MULTIBAND   0   /* models.py:309 Multiband_iSTFT_Generator (fixed PQMF)        */
 #define MBV_DEC_MULTISTREAM 1   /* models.py:387 Multistream_iSTFT_Generator (trainable filter)*/

@@ -22,7 +22,7 @@ SYMBOLS = [
 ]
 
 
-ABI_VERSION = 2             # MBV_ABI_VERSION of include/mbistft_vits.h
+ABI_VERSION = 3             # MBV_ABI_VERSION of include/mbistft_vits.h
 
 
 class MbvConfig(C.Structure):
