@@ -31,7 +31,7 @@ def test_header_symbols_all_exported():
     L = _capi.lib()
     for sym in declared:
         assert getattr(L, sym) is not None
-    assert L.mbv_abi_version() == _capi.ABI_VERSION == 2
+    assert L.mbv_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_config_struct_layout_matches_header():
