@@ -507,6 +507,8 @@ void launch_conv1d_narrow(const ConvArgs& a, bool by_launch_size, hipStream_t s)
   const int tiles_m = (a.M + 31) / 32;
   int nrt = (tiles_m + 3) / 4;
   if (nrt > 6) nrt = 6;               // (fewer row tiles per wave = more row blocks per column tile: measured slower at B = 64)
+  static const int nrt_cap = [] { const char* e = getenv("MBV_NARROW_NRT_CAP"); return e ? atoi(e) : 6; }();
+  if (nrt > nrt_cap) nrt = nrt_cap;
   while (by_launch_size && nrt > 1 && (long)gm.n_ctiles * ((tiles_m + 4 * nrt - 1) / (4 * nrt)) < 384) --nrt;
   // six row tiles (192 channels: the text encoder's conv_o and conv_2) do not divide over four waves: K-split
   // wave pairs of three tiles each (a rule on M alone).  The pairs alternate steps, so a block has an even number.
