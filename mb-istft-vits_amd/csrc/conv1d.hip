@@ -219,7 +219,7 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
 // 2 x 3 MFMA tiles per wave and double-buffered staging as the 128 x 384 shape, two workgroups per CU) that serves
 // convs with <= 64 output rows — the mini configurations' 64-channel stage — instead of the 64 x 128 shape's two
 // accumulators per wave.
-template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2>
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2, int VS = 0>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const ConvArgs a, int tiles_x,
                                                                         int tiles_y, int total_tiles,
                                                                         int ksplit) {
@@ -300,6 +300,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
       int off = -1;                                                                          \
       if (P < 2 * G) {                                                                       \
         int gi = lt0 - a.pad_left + col;                                                     \
+        if constexpr (VS) {     /* virtual column -> (utterance, frame); the gaps read as padding */ \
+          if (gi >= 0) {                                                                     \
+            const int bq_ = gi / a.vs_tv, tq_ = gi - bq_ * a.vs_tv;                          \
+            if (bq_ < a.B && tq_ < a.Tin && (!a.in_lens || tq_ < a.in_lens[bq_]))            \
+              off = bq_ * (int)a.x_bstride + ((P >> 1) * 8 + (P & 1)) * a.x_rstride + tq_;   \
+          }                                                                                  \
+        } else                                                                               \
         if (gi >= 0 && gi < tin_eff) {                                                       \
           if (a.reflect1) gi = gi == 0 ? 1 : gi - 1;                                         \
           if (gi < len_in_) off = ((P >> 1) * 8 + (P & 1)) * a.x_rstride + gi;               \
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
     const int wrow0 = m0 + wm * 32 * WM;
     int nact = (a.M - wrow0 + 31) / 32;              // 32-row tiles of this wave that hold real rows
     nact = nact < 0 ? 0 : (nact > WM ? WM : nact);
-    int nj = (a.T - (t0 + wn * 32 * WN) + 31) / 32;  // ... and 32-column tiles inside the sequence
+    int nj = ((VS ? a.B * a.vs_tv : a.T) - (t0 + wn * 32 * WN) + 31) / 32;  // ... and 32-column tiles inside the sequence
     nj = nj < 0 ? 0 : (nj > WN ? WN : nj);
 
     // Accumulators start from everything the epilogue would otherwise have to READ after the MFMA
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
     }
     // a wave whose 32*WM x 32*WN patch lies wholly inside [M, T] takes the unguarded paths in
     // conv_acc_init and in the epilogue (no per-element exec masking, loads issued back to back)
-    const bool full = wrow0 + 32 * WM <= a.M && t0 + wn * 32 * WN + 32 * WN <= a.T;
+    const bool full = !VS && wrow0 + 32 * WM <= a.M && t0 + wn * 32 * WN + 32 * WN <= a.T;
     const int64_t lane_off = (int64_t)(wrow0 + 4 * hl) * a.T + t0 + wn * 32 * WN + l31;   // element (k = 0, j = 0)
     if (S == 1) {
       conv_acc_init<WM, WN, EPI>(acc, a, b, wrow0, t0, wn, hl, l31, full, lane_off);
@@ -727,6 +734,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
         if (a.convt_u == 4) {
           // lane: column t, rows k (even) and k + 1 of both i-tiles = the 4 output phases of one channel
           const int Tout = 4 * T;
+          int64_t vs_o[VS ? WN : 1];                   // virtual column -> offset of (utterance, 4 x frame) in y
+          bool vs_ok[VS ? WN : 1];
+          if constexpr (VS) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int tv = t0 + wn * 32 * WN + j * 32 + l31;
+              const int bq = tv / a.vs_tv, tq = tv - bq * a.vs_tv;
+              vs_ok[j] = bq < a.B && tq < T;
+              vs_o[j] = (int64_t)bq * a.y_bstride + 4 * (int64_t)tq;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int k = (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -735,6 +753,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
               const int t = t0 + wn * 32 * WN + j * 32 + l31;
+              if constexpr (VS) {
+                if (vs_ok[j]) {
+                  f32x4 o = {acc[0][j][r] + bias, acc[0][j][r + 1] + bias, acc[1][j][r] + bias,
+                             acc[1][j][r + 1] + bias};
+                  *reinterpret_cast<f32x4*>(a.y + vs_o[j] + (int64_t)co * Tout) = o;
+                }
+              } else
               if (t < T) {
                 f32x4 o = {acc[0][j][r] + bias, acc[0][j][r + 1] + bias, acc[1][j][r] + bias,
                            acc[1][j][r + 1] + bias};
@@ -866,7 +891,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
 #undef MBV_GLDS_DRAIN
 }
 
-template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2>
+template <int WM, int WN, int CK, int NWN, int EPI, int PREC = 0, int NWM = 2, int VS = 0>
 static void launch_epi(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = 32 * WM * NWM, BN = 32 * WN * NWN, G = CK / 8, NT = 64 * NWM * NWN;
   const int XL = BN + (a.K - 1) * a.dil;
@@ -874,8 +899,10 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   // prefetch overrun; two buffers for the 512-thread variant
   const size_t buf_f4 = (size_t)G * 2 * XL + (size_t)a.K * G * 2 * BM + 2 * BM;
   const size_t lds_bytes = buf_f4 * 16 * (NWN == 4 ? 2 : 1);
-  const int tiles_x = (a.T + BN - 1) / BN, tiles_y = (a.M + BM - 1) / BM;
-  const long total = (long)tiles_x * tiles_y * a.B;
+  // VS: column tiles run through the batch laid end to end (utterance b at virtual column b * vs_tv); the kernel's
+  // tile decode then yields utterance 0 for every tile and the addressing above does the rest
+  const int tiles_x = VS ? (int)(((long)a.B * a.vs_tv + BN - 1) / BN) : (a.T + BN - 1) / BN, tiles_y = (a.M + BM - 1) / BM;
+  const long total = VS ? (long)tiles_x * tiles_y : (long)tiles_x * tiles_y * a.B;
   // persistent tiles: at most the workgroups that are resident at once (1 per CU for the
   // 512-thread shape, 2 for the 256-thread one: both are register-limited to 2 waves / SIMD)
   static const int persist = [] { const char* e = getenv("MBV_CONV_PERSIST"); return e ? atoi(e) : 1; }();
@@ -914,7 +941,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   a2.debug = dbg | (stg << 8);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM, VS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
 #ifdef MBV_CONV_STAMPS
                               150 * 1024);                        // static LDS: the ticket + 8 KB of stamps
@@ -923,7 +950,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
 #endif
     attr = true;
   }
-  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM>), dim3(grid), dim3(NT), lds_bytes, s, a2,
+  hipLaunchKernelGGL((conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM, VS>), dim3(grid), dim3(NT), lds_bytes, s, a2,
                      tiles_x, tiles_y, (int)total, S);
 }
 
@@ -1069,6 +1096,36 @@ void launch_conv1d(const ConvArgs& a, hipStream_t s) {
         if (nb < 1 || nb >= a.B) continue;
         const double cost = rounds(nb * tpb3, 256) + rounds((a.B - nb) * tpb2, 512) * c2;
         if (cost < 0.9 * best) { best = cost / 0.9; nb_big = (int)nb; }      // (predicted gains below ~10 % did not materialise: B = 96 measured +4 %)
+      }
+    }
+  }
+  // r03: the stride-4 upsampling conv on few, long-ish sequences (T' = 566 input frames: 1.47 tiles of 384 columns, 4.4 of
+  // 128) tiled over the VIRTUAL sequence of the whole batch — utterance b at column b (T + halo), the gaps reading as
+  // zero padding — so that only the last tile of the launch is ragged.  Same chain of operations per output element.
+  {
+    static const int vs_on = [] { const char* e = getenv("MBV_CONV_VS"); return e ? atoi(e) : 1; }();
+    const int halo = (a.K - 1) * a.dil;
+    if (vs_on && a.epi == EPI_CONVT && a.convt_u == 4 && a.prec != 3 && !a.splitk && !a.trim_map && !a.chan_add &&
+        !a.reflect1 && a.B > 1 && a.K > 1 && a.K <= 5 && halo <= 24 && a.T >= 128 &&
+        (int64_t)a.B * a.x_bstride < (1ll << 31)) {
+      auto rounds = [](long n, long slots) { return (double)((n + slots - 1) / slots); };
+      const long tiles_y = (a.M + 127) / 128;
+      const long tv = a.T + halo;
+      const double cost_vs = rounds(((long)a.B * tv + 383) / 384 * tiles_y, 256);
+      double cur;
+      if (nb_big > 0) {
+        const long tpb3 = (long)((a.T + 383) / 384) * tiles_y, tpb2 = (long)((a.T + 127) / 128) * tiles_y;
+        cur = rounds(nb_big * tpb3, 256) + rounds((a.B - nb_big) * tpb2, 512) * 0.65;
+      } else if (big) {
+        cur = rounds((long)((a.T + 383) / 384) * tiles_y * a.B, 256);
+      } else {
+        cur = rounds((long)((a.T + 127) / 128) * tiles_y * a.B, 512) * 0.65;
+      }
+      if (cost_vs >= 2.0 && cost_vs < 0.95 * cur) {
+        ConvArgs av = a;
+        av.vs_tv = (int)tv;
+        launch_epi<2, 3, 16, 4, EPI_CONVT, 0, 2, 1>(av, s);
+        return;
       }
     }
   }

@@ -72,6 +72,9 @@ struct ConvArgs {
   // (column tile, row tile) pairs of that compact list; nothing else changes.  nullptr: every tile (default).
   const int* trim_map;
   int trim_bn;
+  // r03 virtual-sequence tiling (launch_conv1d, EPI_CONVT): > 0 = column tiles run through the batch laid end to end,
+  // utterance b at virtual column b * vs_tv (vs_tv = T + halo); set by the launcher only
+  int vs_tv;
   // split-K scratch (small launches): partial accumulators + one self-resetting ticket per tile
   float* ws;
   size_t ws_floats;
