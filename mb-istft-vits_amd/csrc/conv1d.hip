@@ -518,6 +518,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
     if constexpr (DB) { MBV_ISSUE_NEXT(); }   // second chunk of this tile (its first is in LDS)
+    // Start values that were LOADED: make them land HERE, by the count of loads issued since (straight-line code, so
+    // hipcc emits the exact s_waitcnt vmcnt(n) and the chunk requested above stays in flight).  Without this the
+    // accumulators are "pending vector-memory results" at the head of the step loop, where the counter cannot be
+    // tracked through the chunk loop's control flow: hipcc then puts s_waitcnt vmcnt(0) in front of the first MFMA
+    // of EVERY chunk, which drains the window loads of the chunk after next issued just before it — one exposed global
+    // load latency per chunk (r03, found in the assembly: decoder 40.99 -> 40.77 ms at batch 64, profiles/r03x_acc_pin_ab.txt).
+    if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC || EPI == EPI_RES_SKIP || EPI == EPI_COUPLE) {
+#ifndef MBV_CONV_NO_ACC_PIN               // (the A/B build of profiles/r03x_acc_pin_ab.txt)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(acc[i][j]));
+#endif
+    }
     MBV_CSTAMP(2)                        // start values requested, second chunk requested
 
     for (int c = c_lo; c < c_hi; ++c, ++q) {
@@ -938,7 +952,7 @@ static void launch_epi(const ConvArgs& a, hipStream_t s) {
   ConvArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_CONV_DEBUG"); return e ? atoi(e) : 0; }();
   static const int stg = [] { const char* e = getenv("MBV_CONV_START_STAGGER"); return e ? atoi(e) : 0; }();
-  a2.debug = dbg | (stg << 8);
+  a2.debug = dbg | ((stg & 0xff) << 8);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_mfma_kernel<WM, WN, CK, NWN, EPI, PREC, NWM, VS>),
