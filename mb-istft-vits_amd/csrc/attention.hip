@@ -91,8 +91,24 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
     }
     Qs[e] = v;
   }
+  // relative-key embeddings as the A operand of the logits below, in the same k-interleaved form: [g][h][row], rows
+  // 9 .. 15 zero.  (r03: they used to be read from global memory inside the MFMA chain, `l31 < 9 ? emb_k[..] : 0` —
+  // which hipcc turns into branch, load, s_waitcnt vmcnt(0), MFMA, 48 times in a row: 48 exposed load latencies in the
+  // prologue of every workgroup.)
+  __shared__ f32x4 Eks[QG * 2 * 16];
+  for (int e = threadIdx.x; e < QG * 2 * 16; e += 64 * NW) {
+    const int g = e >> 5, h = (e >> 4) & 1, row = e & 15;
+    f32x4 v;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kk = 2 * (4 * g + s4) + h;
+      v[s4] = (row < 9 && kk < d) ? emb_k[row * d + kk] : 0.f;
+    }
+    Eks[e] = v;
+  }
   __syncthreads();
   const f32x4* const ql = Qs + hl * 32 + l31;          // + 64 g
+  const f32x4* const el = Eks + hl * 16 + min(l31, 15);   // + 32 g (lanes 16 .. 31 read the zero row 15)
 
   // ---- relative-key logits: R^T[r][tq] = sum_d Ek[r][d] q[d][tq] ------------
   // (four interleaved MFMA chains: an fp32 32x32x2 MFMA feeds the next one on the same accumulator only
@@ -105,13 +121,12 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       const f32x4 qv = ql[64 * g];
+      const f32x4 ev = el[32 * g];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        // (k-steps past the head dimension multiply the zeros of the Q image: no test between the MFMAs)
-        const int kk = min(2 * (4 * g + s4) + hl, d - 1);
-        const float av = l31 < 9 ? emb_k[l31 * d + kk] : 0.f;
-        if (s4 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qv[s4], acc, 0, 0, 0);
-        else accb[s4 - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qv[s4], accb[s4 - 1], 0, 0, 0);
+        // (k-steps past the head dimension multiply zeros by zeros: no test between the MFMAs)
+        if (s4 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[s4], qv[s4], acc, 0, 0, 0);
+        else accb[s4 - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[s4], qv[s4], accb[s4 - 1], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -248,6 +263,19 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
   sum += __shfl_xor(sum, 32);
 #pragma unroll
   for (int q = 0; q < 9; ++q) wb[q] += __shfl_xor(wb[q], 32);
+  // Relative values: O^T += Ev^T W, one more contraction over the 9 (padded to 10) relative positions on the matrix
+  // pipe: A[dd][q] = emb_v[q][dd] (15 coalesced loads per lane, requested here, used after the waves are folded),
+  // B[q][tq] = the band weights every lane holds for its own query.  (r03: this used to be, per accumulator
+  // register, `if (dd < d && tq < T) { 9 loads of emb_v; 9 fma; store }` — 48 rounds of loads behind the previous
+  // round's store, each waited for in full: most of the kernel's tail.)
+  float evf[5][DT];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int q = 2 * s + hl, dd = t * 32 + l31;
+      evf[s][t] = (q < 9 && dd < d) ? emb_v[q * d + dd] : 0.f;
+    }
 
   // ---- fold the waves' partial (m, l, O^T, band weights) into wave 0 -------------------------
   __syncthreads();                                    // every wave is done with its V tile
@@ -299,18 +327,20 @@ __global__ __launch_bounds__(64 * ATT_NW, 2) void rel_attention_kernel(const flo
   }
 
   // ---- relative values + store ------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const float w_lo = wb[2 * s], w_hi = 2 * s + 1 < 9 ? wb[2 * s + 1 < 9 ? 2 * s + 1 : 8] : 0.f;
+    const float bw = hl ? w_hi : w_lo;                 // B[k = hl][j = l31]: band weight 2 s + hl of query l31
+#pragma unroll
+    for (int t = 0; t < DT; ++t) O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(evf[s][t], bw, O[t], 0, 0, 0);
+  }
   float* ob = o + ((int64_t)b * H + head * d) * T;
 #pragma unroll
   for (int t = 0; t < DT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int dd = t * 32 + acc_row(r, hl);
-      if (dd < d && tq < T) {
-        float v = O[t][r];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) v = fmaf(wb[q], emb_v[q * d + dd], v);
-        ob[(int64_t)dd * T + tq] = v;
-      }
+      if (dd < d && tq < T) ob[(int64_t)dd * T + tq] = O[t][r];
     }
   }
 }

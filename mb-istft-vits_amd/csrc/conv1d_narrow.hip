@@ -171,20 +171,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       for (int j = 0; j < NRT; ++j) {
         const int row0 = MBV_ROW0(j);
 #pragma unroll
+        // Every load below is UNCONDITIONAL: an absent operand is a zero-sized buffer (its loads return 0), a tile
+        // slot past M reads values nobody stores.  With `if (row0 < M) x += load` in this nest (r02) hipcc emitted
+        // branch, load, s_waitcnt vmcnt(0) per element — 16 NRT (running sum: 32 NRT) memory round trips one after the
+        // other at the start of every unit (r03, scripts/asm_serial_loads.py); now they are one batch.
         for (int q = 0; q < 4; ++q) {
           f32x4 v = bload4(b_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);  // past M / no bias: reads 0
-          if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) {
-            if (a.res_chan_add && row0 < M) v += bload4(rc_rs, rc_voff, (unsigned)(row0 + 8 * q) * 4u);
-          }
+          if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) v += bload4(rc_rs, rc_voff, (unsigned)(row0 + 8 * q) * 4u);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             float x = v[s];
-            if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) {
-              if (row0 < M) {
-                x += bload1(r_rs, r_voff, (unsigned)(row0 + 8 * q + s) * rowT);
-                if (EPI == EPI_RESID_ACC && a.accum_in) x += bload1(ac_rs, y_voff, (unsigned)(row0 + 8 * q + s) * rowT);
-              }
-            }
+            if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_ACC) x += bload1(r_rs, r_voff, (unsigned)(row0 + 8 * q + s) * rowT);
+            if constexpr (EPI == EPI_RESID_ACC) x += bload1(ac_rs, y_voff, (unsigned)(row0 + 8 * q + s) * rowT);
             acc[j][4 * q + s] = x;
           }
         }
@@ -363,27 +361,49 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       const unsigned r_voff = tv ? (unsigned)(b * (int)a.res_bstride + 4 * hl * T + t) * 4u : kOob;
       const bool keep = !a.out_lens || t < a.out_lens[b];
       float part = 0.f;
+      // the residual of row tile j + 1 is requested (16 loads in one batch, unconditional: no residual = a zero-sized
+      // buffer) before row tile j is worked on; nothing in the arithmetic below branches.  (r02 had `if (a.res && ..) v +=
+      // load` between an `if (a.relu)` and an `if (row0 >= M)`: hipcc kept every load in its own basic block and waited
+      // for it there — 16 NRT memory round trips in a row in every unit's epilogue.)
+      const float relu_floor = a.relu ? 0.f : -INFINITY;
+      float rv[2][16];
+#define MBV_LN_RES(J, BUF)                                                                      \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r)                                            \
+        rv[BUF][r] = bload1(r_rs, r_voff, (unsigned)(MBV_ROW0(J) + (r & 3) + 8 * (r >> 2)) * rowT);
+      MBV_LN_RES(0, 0)
 #pragma unroll
       for (int j = 0; j < NRT; ++j) {
         const int row0 = MBV_ROW0(j);
+        if (j + 1 < NRT) { MBV_LN_RES(j + 1, (j + 1) & 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        const float live = row0 >= M ? 0.f : 1.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int k = (r & 3) + 8 * (r >> 2);
           float v = acc[j][r];
           if constexpr (kExtra == 1) v += acc2[j][r];
           if constexpr (kExtra == 3) v = (v + acc2[j][r]) + (acc2[NRT + j][r] + acc2[2 * NRT + j][r]);
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (!keep) v = 0.f;
-          if (a.res && row0 < M) v += bload1(r_rs, r_voff, (unsigned)(row0 + k) * rowT);
-          if (row0 >= M) v = 0.f;
+          v = fmaxf(v, relu_floor);
+          v = keep ? v : 0.f;
+          v += rv[j & 1][r];
+          v = live != 0.f ? v : 0.f;
           acc[j][r] = v;
           part += v;
         }
       }
+#undef MBV_LN_RES
       part += __shfl_xor(part, 32);
       float* red = lds;                                                // [2][4 waves][32 frames]
+      // gamma / beta through LDS ([M] each, behind the statistics): read back below by ds_read_b128 between the stores.
+      // (As buffer loads inside the store loop — r02 — every (tile, q) pair of loads queued behind the four stores before
+      // it on the one in-order memory counter and was waited for in full: 4 NRT store round trips per unit.)
+      float* const gam_s = lds + 256;
+      float* const bet_s = gam_s + M;
       __syncthreads();                                                 // every wave is done with the input window
       if (hl == 0) red[wave * 32 + l31] = part;
+      for (int e = tid; e < M; e += 256) {
+        gam_s[e] = bload1(g_rs, (unsigned)e * 4u, 0);
+        bet_s[e] = bload1(be_rs, (unsigned)e * 4u, 0);
+      }
       __syncthreads();
       const float mean = (red[l31] + red[32 + l31] + red[64 + l31] + red[96 + l31]) / (float)M;
       float sq = 0.f;
@@ -408,7 +428,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
         if (row0 >= M) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 gq = bload4(g_rs, bvo, (unsigned)(row0 + 8 * q) * 4u), bq = bload4(be_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(gam_s + row0 + 8 * q + 4 * hl);
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bet_s + row0 + 8 * q + 4 * hl);
 #pragma unroll
           for (int s2 = 0; s2 < 4; ++s2)
             bstore1(((acc[j][4 * q + s2] - mean) * rstd * gq[s2] + bq[s2]) * lm, y_rs, y_voff, (unsigned)(row0 + 8 * q + s2) * rowT);
@@ -448,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
 template <int NRT, int EPI, bool KS = false>
 void launch_narrow_t(const ConvArgs& a, const NarrowGeom& gm, hipStream_t s) {
   size_t lds_bytes = (size_t)(gm.CB / 8) * 2 * 2 * gm.XS * 16;
+  if (EPI == EPI_LN && lds_bytes < (size_t)(256 + 2 * a.M) * 4) lds_bytes = (size_t)(256 + 2 * a.M) * 4;   // statistics + gamma / beta
   if (KS && lds_bytes < (size_t)2 * NRT * 16 * 64 * 4) lds_bytes = (size_t)2 * NRT * 16 * 64 * 4;   // the pairs' hand-over
   const long units = (long)gm.n_ctiles * gm.n_rblk;
   const int grid = (int)(units < 512 ? (units < 1 ? 1 : units) : 512);

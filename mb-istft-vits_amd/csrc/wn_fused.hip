@@ -226,33 +226,45 @@ __device__ __forceinline__ void rs_ring_init(f32x4 (&rb)[kDR][NRT], const WnCtx&
 // (r & 3) + 8 (r >> 2) + 4 hl.  The residual rows' start values (h of the tile's own frames) are
 // already in LDS: the centre of the input window (channel ch -> image row (ch / 8) * 2 + (ch & 1),
 // component (ch & 7) >> 1); masked frames hold 0 there.  skip comes from memory (masked lanes read 0).
+// Two parts, nothing in either is conditional (r03, after the assembly audit of scripts/asm_serial_loads.py: with
+// `if (row0 < Mr) { if (is_res) .. else if (skip_accum) v += load }` in one nest hipcc emitted branch, load,
+// s_waitcnt vmcnt(0) per element — up to 20 memory round trips per tile, one after the other, in every unit):
+//   rs_acc_request: the skip start values, loaded straight into the accumulators (no temporaries: the kernel has no
+//     registers to spare here) — a tile that takes none loads through an out-of-range lane offset and gets zeros;
+//     issued BEFORE the gating arithmetic, which hides the one batch;
+//   rs_acc_finish (after the gating, when its accumulators are dead): + bias (from LDS, staged once per workgroup)
+//     + the residual rows' own input (the window centre in LDS; times 0 for tiles that take none).
 template <int NRT>
-__device__ __forceinline__ void rs_acc_init(f32x16 (&acr)[NRT], const f32x4* Xs, const WnCtx& c) {
-  const unsigned bvo = (unsigned)(4 * c.hl) * 4u;
-  const float* xc = reinterpret_cast<const float*>(Xs + c.xoff + (kK - 1) / 2);
+__device__ __forceinline__ void rs_acc_request(f32x16 (&acr)[NRT], const WnCtx& c) {
 #pragma unroll
   for (int j = 0; j < NRT; ++j) {
     const int row0 = (c.wave + 4 * j) * 32;
     const bool is_res = !c.last && row0 < c.H;                  // wave-uniform (H % 32 == 0)
     const unsigned srow0 = (unsigned)(c.last ? row0 : row0 - c.H);
+    const unsigned sko = (row0 < c.Mr && !is_res && c.skip_accum) ? c.sk_voff : kOob;   // (row0 >= Mr: an idle tile slot, see rs_store)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acr[j][r] = bload1(c.skip_rs, sko, (srow0 + 8 * (r >> 2) + (r & 3)) * c.rowT);
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void rs_acc_finish(f32x16 (&acr)[NRT], const f32x4* Xs, const float* Bs, const WnCtx& c) {
+  const float* xc = reinterpret_cast<const float*>(Xs + c.xoff + (kK - 1) / 2);
+#pragma unroll
+  for (int j = 0; j < NRT; ++j) {
+    const int row0 = (c.wave + 4 * j) * 32;
+    const bool use_x = row0 < c.Mr && !c.last && row0 < c.H && !c.prefold;
+    const float xw = use_x ? 1.f : 0.f;
+    const int rowx = use_x ? row0 : 0;                           // (keeps the LDS reads inside the window image)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 bq = bload4(c.br_rs, bvo, (unsigned)(row0 + 8 * q) * 4u);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(Bs + row0 + 8 * q + 4 * c.hl);   // rows past Mr: zeros
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int r = 4 * q + s;
-        float v = bq[s];
-        if (row0 < c.Mr) {                                      // (an idle tile slot: see rs_store)
-          if (is_res) {
-            if (!c.prefold) {
-              const int ch = row0 + 8 * q + 4 * c.hl + s;       // (ch & 7) = 4 hl + s
-              v += xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
-            }
-          } else if (c.skip_accum) {
-            v += bload1(c.skip_rs, c.sk_voff, (srow0 + 8 * q + s) * c.rowT);
-          }
-        }
-        acr[j][r] = v;
+        const int ch = rowx + 8 * q + 4 * c.hl + s;             // (ch & 7) = 4 hl + s
+        const float xv = xc[(((ch >> 3) * 2 + (s & 1)) * kXL) * 4 + 2 * c.hl + (s >> 1)];
+        acr[j][r] = (acr[j][r] + bq[s]) + xw * xv;
       }
     }
   }
@@ -372,6 +384,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
   const int in_cb = a.in_cb ? a.in_cb : H;
   f32x4* const Xs = reinterpret_cast<f32x4*>(lds);          // [Gi][2][kXL]
   f32x4* const As = Xs + Gi * 2 * kXL;                       // [G][2][32]
+  float* const Bs = reinterpret_cast<float*>(As + G * 2 * 32);   // [128 NRT]: bias of the res / skip conv, zeros past Mr
+  for (int e = tid; e < 128 * NRT; e += 256) Bs[e] = e < a.Mr && a.br ? a.br[e] : 0.f;   // (read after the unit loop's barriers)
   const int Hn = a.ustart[a.B];                // half-units of the batch
   const int U = (Hn + 1) / 2;                  // tiles
 
@@ -462,8 +476,9 @@ __global__ __launch_bounds__(256, 2) void wn_layer_kernel(const WnLayerArgs a) {
     f32x4 rb[kDR][NRT];
     rs_ring_init<NRT>(rb, c);        // both issued before the gating arithmetic, which hides their latency
     f32x16 acr[NRT];
-    rs_acc_init<NRT>(acr, Xs, c);
+    rs_acc_request<NRT>(acr, c);
     gate_act<NRT>(acc, As, c);
+    rs_acc_finish<NRT>(acr, Xs, Bs, c);
     __syncthreads();
 
     rs_loop<NRT>(acr, rb, As, c);
@@ -481,8 +496,8 @@ bool wn_fused_supported(int H, int K) {
 
 void launch_wn_layer(const WnLayerArgs& a, hipStream_t s) {
   const int G = a.H / 8, Gi = a.Gi ? a.Gi : G;
-  const size_t lds_bytes = (size_t)(Gi * 2 * kXL + G * 2 * 32) * 16;
   const int nrt = (2 * a.H / 32 + 3) / 4;
+  const size_t lds_bytes = (size_t)(Gi * 2 * kXL + G * 2 * 32) * 16 + (size_t)128 * (nrt <= 2 ? 2 : 3) * 4;   // + the res / skip bias
   WnLayerArgs a2 = a;
   static const int dbg = [] { const char* e = getenv("MBV_WN_DEBUG_A"); return e ? atoi(e) : 0; }();
   a2.debug = dbg;                    // experiments: 1 = every step reads the weights of step 0 (timing only, results wrong);
