@@ -109,28 +109,49 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
                                               int t0, int wn, int hl, int l31, bool full,
                                               int64_t lane_off) {
   constexpr bool kInit = EPI == EPI_RESID || EPI == EPI_RESID_ACC || EPI == EPI_RES_SKIP || EPI == EPI_COUPLE;
-    if ((EPI == EPI_RESID || EPI == EPI_RESID_ACC) && full) {
-      const float* pr = a.res + (int64_t)b * a.res_bstride + lane_off;
+    if ((EPI == EPI_RESID || EPI == EPI_RESID_ACC) && wrow0 + 32 * WM <= a.M) {
+      // Every row real (any patch of the decoder's convs).  Loads through a buffer view of the utterance: one 32-bit
+      // lane offset per column tile — out of range for a lane whose column lies past the end of the sequence, which
+      // then reads 0 — plus a scalar row offset: no 64-bit address per element, and the edge patches (the last column
+      // tile of an utterance) take the same batched loads as interior ones.  In the per-element form at the bottom
+      // (`if (row < M && t < T) { v0 = res[..]; if (accum_in) v0 += accum_in[..]; }`) hipcc emits branch, load,
+      // s_waitcnt vmcnt(0) per element for the running-sum variant: 96 memory round trips one after the other in a wave
+      // of every edge tile, and the workgroups holding one end the launch that much later (r03 audit,
+      // scripts/asm_serial_loads.py).
+      const unsigned long long nbytes = (unsigned long long)a.M * a.T * 4ull;
+      const unsigned nrec = nbytes > 0xfffffffcull ? 0xfffffffcu : (unsigned)nbytes;
+      const __amdgpu_buffer_rsrc_t rr =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res + (int64_t)b * a.res_bstride), 0, nrec, 0x00020000);
+      unsigned vo[WN];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int t = t0 + wn * 32 * WN + j * 32 + l31;
+        vo[j] = t < a.T ? (unsigned)((wrow0 + 4 * hl) * a.T + t) * 4u : 0x7fffffffu;
+      }
+      const unsigned rowT = (unsigned)a.T * 4u;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float* q = pr + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+          const unsigned so = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowT;
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j][r] = q[j * 32];
+          for (int j = 0; j < WN; ++j)
+            acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)vo[j], (int)so, 0));
         }
       if (EPI == EPI_RESID_ACC && a.accum_in) {
         // second operand through temporaries, half a patch at a time: two waits instead of one
         // per element (a load feeding an add right away serialises the whole initialisation)
-        const float* pa = a.accum_in + (int64_t)b * a.y_bstride + lane_off;
+        const __amdgpu_buffer_rsrc_t ra =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.accum_in + (int64_t)b * a.y_bstride), 0, nrec, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
           float tmp[16][WN];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float* q = pa + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * a.T;
+            const unsigned so = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * rowT;
 #pragma unroll
-            for (int j = 0; j < WN; ++j) tmp[r][j] = q[j * 32];
+            for (int j = 0; j < WN; ++j)
+              tmp[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)vo[j], (int)so, 0));
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r)
