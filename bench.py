@@ -356,7 +356,7 @@ def main():
         set_bytes = ISTFT_BYTES_PER_FRAME * frames
         nsets = max(3, int(np.ceil(3.0 * 256 * 2 ** 20 / set_bytes)))
         cold_ms = istft_waveform_only_ms(net, B, Tp, iters=50, rotate=nsets)
-        all_ms = float(np.mean(istft_ms))
+        all_ms = float(np.median(istft_ms))
         ach = set_bytes / (wave_ms * 1e-3) / 1e9
         ach_cold = set_bytes / (cold_ms * 1e-3) / 1e9
         ach_all = ISTFT_BYTES_PER_FRAME_ALL * frames / (all_ms * 1e-3) / 1e9
@@ -383,11 +383,14 @@ def main():
     if rank == 0:
         frames = B * Tp
         fl = decoder_flops_per_frame(cfg) * frames
-        cm = float(np.mean(conv_ms))
+        # median of the per-step HIP-event readings (r03z: one stalled step of ten moved the MEAN by 2 ms, 0.82 -> 0.78,
+        # while the timed region next to it and the run after it on the same box read 40.5 ms); min / max printed beside it
+        cm = float(np.median(conv_ms))
         roof_conv = {"kernel": "decoder conv stack (conv1d_mfma, fp32 MFMA)", "bound": "mfma",
                      "achieved": round(fl / (cm * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(fl / (cm * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-                     "ms_per_step": round(cm, 3), "flop_per_step": fl}
+                     "ms_per_step": round(cm, 3), "ms_per_step_min_max": [round(float(np.min(conv_ms)), 3), round(float(np.max(conv_ms)), 3)],
+                     "samples": len(conv_ms), "flop_per_step": fl}
         pmc_conv = os.path.join(ROOT, "profiles", "conv_mfma_pmc.json")
         if os.path.isfile(pmc_conv):             # matrix-pipe busy share from a separate --pmc pass
             pj = json.load(open(pmc_conv))
