@@ -150,6 +150,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
       hb[k] = huc / gm.hpu;
       ht0[k] = (huc - hb[k] * gm.hpu) * kHalf;
     }
+    // input lengths of the two half-units' utterances, looked up ONCE per unit.  (Inside the staging loop —
+    // `a.in_lens ? min(a.in_lens[bb], a.Tin) : a.Tin` per item, r02 — every item's lookup was a load followed by
+    // s_waitcnt vmcnt(0), which also drained the window loads of the item before it: the staging of a channel block
+    // was 2 NXI dependent memory round trips instead of one batch.  r03 audit)
+    int lim_h[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)          // (readfirstlane: a scalar load — it must not sit on the vector-memory counter in front of the staging loop)
+      lim_h[k] = a.in_lens ? min(a.in_lens[__builtin_amdgcn_readfirstlane(hb[k])], a.Tin) : a.Tin;
     const int b = half ? hb[1] : hb[0];
     const int t = (half ? ht0[1] : ht0[0]) + jl;                       // this lane's output frame
     const bool tv = (half ? hok[1] : hok[0]) && t < T;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_narrow_kernel(const ConvArgs a,
             const int k = cc >= gm.XS, c2 = cc - k * gm.XS;
             const int bb = k ? hb[1] : hb[0];
             const int ti = (k ? ht0[1] : ht0[0]) - a.pad_left + c2;
-            const int lim = a.in_lens ? min(a.in_lens[bb], a.Tin) : a.Tin;
+            const int lim = k ? lim_h[1] : lim_h[0];
             const int ch = (g0 + (P >> 1)) * 8 + (P & 1);
             const bool ok = e < items && c2 < W && (k ? hok[1] : hok[0]) && ti >= 0 && ti < lim;
             const unsigned vo = ok ? (unsigned)(bb * (int)a.x_bstride + ch * a.x_rstride + ti) * 4u : kOob;
