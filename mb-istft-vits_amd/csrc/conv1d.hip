@@ -118,8 +118,7 @@ __device__ __forceinline__ void conv_acc_init(f32x16 (&acc)[WM][WN], const ConvA
       // s_waitcnt vmcnt(0) per element for the running-sum variant: 96 memory round trips one after the other in a wave
       // of every edge tile, and the workgroups holding one end the launch that much later (r03 audit,
       // scripts/asm_serial_loads.py).
-      const unsigned long long nbytes = (unsigned long long)a.M * a.T * 4ull;
-      const unsigned nrec = nbytes > 0xfffffffcull ? 0xfffffffcu : (unsigned)nbytes;
+      const unsigned nrec = (unsigned)a.M * (unsigned)a.T * 4u;   // < 4 GiB: checked by launch_conv1d
       const __amdgpu_buffer_rsrc_t rr =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res + (int64_t)b * a.res_bstride), 0, nrec, 0x00020000);
       unsigned vo[WN];
@@ -1072,6 +1071,11 @@ int conv1d_trim_bn(const ConvArgs& a) {
 }
 
 void launch_conv1d(const ConvArgs& a, hipStream_t s) {
+  // (the residual / running-sum start values are read through a 32-bit buffer view of one utterance, conv_acc_init)
+  if ((a.epi == EPI_RESID || a.epi == EPI_RESID_ACC) && (unsigned long long)a.M * a.T * 4ull >= (1ull << 32)) {
+    fprintf(stderr, "mbv: conv1d: one utterance's [%d x %d] output exceeds 4 GiB\n", a.M, a.T);
+    abort();
+  }
   // conv1d_narrow.hip (32-column units, rows split over waves, weights from L2) takes over where the
   // 128-column tiles below fit badly:
   //   (a) every sequence of <= 256 frames (the text encoder, the duration predictor): T = 200 fills
