@@ -646,7 +646,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
           if constexpr (PREC == 3) {
             if (nj > 0) { MBV_BF16_LOOP() }
           } else if constexpr (NWN == 2) {
-            if (nj == WN) MBV_STEP_LOOP(true) else MBV_STEP_LOOP(false)
+            // (r03: one loop for every wave that holds a real column, as in the 512-thread shape — columns past the end of
+            // the sequence are staged as zeros and never stored.  The per-MFMA `j < nj` form that edge patches used to
+            // take compiled to a scalar branch around every MFMA, and carrying a second loop body cost registers.)
+            if (nj > 0) MBV_STEP_LOOP(true)
           } else {
             // 512-thread shape: no column test at all — columns past the end of the sequence are
             // staged as zeros and never stored, so the few MFMAs they cost on the last tile of a row
