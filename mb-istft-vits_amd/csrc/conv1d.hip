@@ -643,7 +643,40 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
               _Pragma("unroll") for (int j = 0; j < WN; ++j)                                               \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);     \
           }
-          if constexpr (PREC == 3) {
+          if constexpr (EPI == EPI_CONVT && G == 2 && PREC == 0 && NWN == 4) {   // (256-thread shape: 31 registers spilled)
+            // The polyphase ConvTranspose skips the row tile whose weights are structurally zero at the first / last
+            // tap.  With the skip decided per MFMA at run time (`i != sk_` inside MBV_MMA, sk_ a function of the
+            // step) hipcc put a scalar branch around EVERY MFMA of the loop (r03 assembly audit: 24 branches per
+            // step; the two upsampling convs ran at 0.77 of peak against 0.85 for the k = 7 convs).  The stride-4
+            // form has exactly ten steps (5 taps x 2 groups): written out, every skip is a compile-time fact.
+            if (nj > 0 && a.K == 5) {
+              MBV_LOAD_AB(0, a0, b0);
+#pragma unroll
+              for (int st = 0; st < 10; st += 2) {
+                MBV_LOAD_AB(st + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_MMA(a0, b0, (st / 2 == 0 ? 1 : (st / 2 == 4 ? 0 : -1)), true);
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_LOAD_AB(st + 2, a0, b0); /* last pass: one step past the slab (padded, unused) */
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_MMA(a1, b1, (st / 2 == 0 ? 1 : (st / 2 == 4 ? 0 : -1)), true);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            } else if (nj > 0 && a.K == 3) {     // stride 8 (single-band decoder): six steps
+              MBV_LOAD_AB(0, a0, b0);
+#pragma unroll
+              for (int st = 0; st < 6; st += 2) {
+                MBV_LOAD_AB(st + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_MMA(a0, b0, (st / 2 == 0 ? 1 : (st / 2 == 2 ? 0 : -1)), true);
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_LOAD_AB(st + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                MBV_MMA(a1, b1, (st / 2 == 0 ? 1 : (st / 2 == 2 ? 0 : -1)), true);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            } else if (nj > 0) MBV_STEP_LOOP(true)
+          } else if constexpr (PREC == 3) {
             if (nj > 0) { MBV_BF16_LOOP() }
           } else if constexpr (NWN == 2) {
             // (r03: one loop for every wave that holds a real column, as in the 512-thread shape — columns past the end of
@@ -655,27 +688,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
             // staged as zeros and never stored, so the few MFMAs they cost on the last tile of a row
             // buy a loop without exec-mask juggling around every MFMA
             static_assert(NWN == 4, "");
-            if constexpr (EPI == EPI_CONVT && G == 2) {
-              // The polyphase ConvTranspose skips the row tile whose weights are structurally zero at the first / last
-              // tap.  With the skip decided per MFMA at run time (`i != sk_` inside MBV_MMA, sk_ a function of the
-              // step) hipcc put a scalar branch around EVERY MFMA of the loop (r03 assembly audit: 24 branches per
-              // step; the two upsampling convs ran at 0.77 of peak against 0.85 for the k = 7 convs).  The stride-4
-              // form has exactly ten steps (5 taps x 2 groups): written out, every skip is a compile-time fact.
-              if (nj > 0 && a.K == 5) {
-                MBV_LOAD_AB(0, a0, b0);
-#pragma unroll
-                for (int st = 0; st < 10; st += 2) {
-                  MBV_LOAD_AB(st + 1, a1, b1);
-                  __builtin_amdgcn_sched_barrier(0);
-                  MBV_MMA(a0, b0, (st / 2 == 0 ? 1 : (st / 2 == 4 ? 0 : -1)), true);
-                  __builtin_amdgcn_sched_barrier(0);
-                  MBV_LOAD_AB(st + 2, a0, b0); /* last pass: one step past the slab (padded, unused) */
-                  __builtin_amdgcn_sched_barrier(0);
-                  MBV_MMA(a1, b1, (st / 2 == 0 ? 1 : (st / 2 == 4 ? 0 : -1)), true);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-              } else if (nj > 0) MBV_STEP_LOOP(true)
-            } else
             if (nj > 0) MBV_STEP_LOOP(true)
           }
 #undef MBV_BF16_LOOP

@@ -1,10 +1,12 @@
 #!/bin/bash
+# (CFGS="cfg batch;cfg batch" overrides the configuration list)
 # usage: r03_cfg_ab.sh <tag> "<ENV=a>" "<ENV=b>" ...   other configurations' ms per step / conv-stack fraction per variant (same box, alternating)
 set -o pipefail
 VARS=("${@:2}")
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; tag=$1; shift; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R
 : > $O/cfg_ab.txt
-for cb in "uudb_ms_istft_vits_ms 32" "ljs_mini_mb_istft_vits 64" "ljs_mb_istft_vits 16" "ljs_mb_istft_vits 48" "ljs_mini_istft_vits 64"; do
+IFS=";" read -ra CF <<< "${CFGS:-uudb_ms_istft_vits_ms 32;ljs_mini_mb_istft_vits 64;ljs_mb_istft_vits 16;ljs_mb_istft_vits 48;ljs_mini_istft_vits 64}"
+for cb in "${CF[@]}"; do
   set -- $cb; cfg=$1; b=$2
   for rep in 1 2; do
     for v in "${VARS[@]}"; do
