@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
     const int cn_ = (CN);                                                                    \
     const float* wchunk = wlane + (int64_t)(cn_ / 8) * 2 * a.Mpad * 4;                       \
     if constexpr (!GLDS) {                                                                   \
+    if (a.debug != 5 || cn_ == 0)     /* (ablation 5: weights staged for a tile's first chunk only; timing) */ \
     _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
       int64_t off;                                                                           \
       if constexpr (RPI >= ROWS_PER_TAP) {                                                   \
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void conv1d_mfma_kernel(const Co
   {                                                                                          \
     const int cn_ = (CN);                                                                    \
     if constexpr (!GLDS) {                                                                   \
+    if (a.debug != 5 || cn_ == 0)                                                            \
     _Pragma("unroll") for (int u = 0; u < NW; ++u) {                                         \
       const int e = tid + NT * u;                                                            \
       if (e < totalW) (WS)[e] = wreg[u];           /* LDS order == copy order */             \
