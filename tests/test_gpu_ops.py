@@ -443,7 +443,7 @@ def test_fused_wn_layer_kernel_against_cpu_loop(tmp_path):
 def test_rel_attention_kernel_against_the_oracle_op():
     """`rel_attention_kernel` on its own (the attention was only covered through x_enc and the durations):
     random q | k | v and relative embeddings, ragged lengths incl. a 1-token and a full-length utterance, T across the
-    32-key tile boundaries, head dimensions 96 and 48 — against the oracle's `relative_attention` (attentions.py:148-243
+    32-key tile boundaries, head dimensions 96, 48, 40 and 32 — against the oracle's `relative_attention` (attentions.py:148-243
     restated: -1e4 mask fill, window of +-4, q scaled before both the content and the relative logits)."""
     import ctypes as C
     from gpu_util import make_net, ptr
@@ -452,7 +452,10 @@ def test_rel_attention_kernel_against_the_oracle_op():
     net = make_net("ljs_mini_mb_istft_vits")[0]
     h = net._ensure_handle()
     g = torch.Generator().manual_seed(7)
-    for (B, H, heads, T) in ((3, 192, 2, 200), (2, 96, 2, 33), (4, 192, 2, 64), (1, 192, 2, 1), (2, 192, 2, 257)):
+    # (r03: + head dimensions 32 and 40 — a head that ends inside a 32-row tile exercises the `kk < d` / `dd < d` guards of the
+    # LDS-staged relative-key image and of the relative-value contraction)
+    for (B, H, heads, T) in ((3, 192, 2, 200), (2, 96, 2, 33), (4, 192, 2, 64), (1, 192, 2, 1), (2, 192, 2, 257),
+                             (2, 64, 2, 70), (3, 80, 2, 45)):
         d = H // heads
         qkv = torch.randn(B, 3 * H, T, generator=g)
         ek, ev = torch.randn(9, d, generator=g) * 0.3, torch.randn(9, d, generator=g) * 0.3
